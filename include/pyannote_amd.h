@@ -1,0 +1,102 @@
+/* pyannote_amd.h -- C ABI of libpyannote_amd.so (gfx950 / MI355X kernels for the
+ * speaker-diarization-3.1 hot path).
+ *
+ * The reference (pyannote.audio 4.0.x) is 100 % Python and has NO C/FFI boundary of its own
+ * (SURVEY.md section 8b); the boundary below is what the reference's Python objects would bind with
+ * `ctypes` (see INTEGRATION.md for the stubs).  Each group cites the reference interface it
+ * replaces, relative to src/pyannote/audio/.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless its name ends in `_host` or it is uint8;
+ *     (`tensor.data_ptr()` of a contiguous torch-ROCm tensor is what callers pass)
+ *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); nothing synchronises
+ *   - no hidden allocation: scratch comes from the caller (`*_workspace_bytes`)
+ *   - return 0 = OK, 1 = launch/runtime failure, 2 = out of memory, 3 = invalid argument;
+ *     pa_last_error() returns a thread-local message.  Python maps 2 -> MemoryError, which is the
+ *     convention of Inference.infer (core/inference.py:199-208).
+ *   - all arithmetic is IEEE fp32 (f32-input MFMA; the reference disables TF32,
+ *     utils/reproducibility.py:68-73); the clustering distance kernels are fp64 like SciPy.
+ */
+#ifndef PYANNOTE_AMD_H
+#define PYANNOTE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int pa_version(void);
+const char* pa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Segmentation model: replaces PyanNet.forward (models/segmentation/PyanNet.py:211-240) +
+ * Powerset.to_multilabel(hard) (utils/powerset.py:115-140) as called from Inference.infer
+ * (core/inference.py:182-215).
+ * ---------------------------------------------------------------------------------------- */
+#define PA_MAX_LSTM_LAYERS 8
+#define PA_MAX_LINEAR 4
+
+typedef struct pa_seg_weights {
+  int32_t sinc_stride;   /* 10 */
+  int32_t lstm_layers;   /* L */
+  int32_t lstm_hidden;   /* 128 (only value built) */
+  int32_t lstm_bidir;    /* 1 */
+  int32_t num_linear;    /* 0..PA_MAX_LINEAR */
+  int32_t linear_hidden; /* 128 */
+  int32_t num_classes;   /* powerset classes (7) */
+  int32_t num_speakers;  /* multilabel width (3) */
+  float wav_gamma, wav_beta;  /* sincnet.wav_norm1d.{weight,bias} */
+  const float* sinc_filt; /* [5][63][64]  MFMA B image of the 80x251 sinc taps (tap 251 = 0) */
+  const float* norm0;     /* [2][80] gamma | beta  (sincnet.norm1d.0) */
+  const float* conv1_w;   /* [4][100][64] MFMA B image of sincnet.conv1d.1.weight (60,80,5) */
+  const float* conv1_b;   /* [64] (60 real) */
+  const float* norm1;     /* [2][60] */
+  const float* conv2_w;   /* [4][75][64]  image of sincnet.conv1d.2.weight (60,60,5) */
+  const float* conv2_b;   /* [64] */
+  const float* norm2;     /* [2][60] */
+  const float* lstm_wih[PA_MAX_LSTM_LAYERS];  /* [1024][Kin] rows permuted, Kin = 64 (layer 0) / 256 */
+  const float* lstm_bias[PA_MAX_LSTM_LAYERS]; /* [1024] b_ih + b_hh, permuted */
+  const float* lstm_whh[PA_MAX_LSTM_LAYERS];  /* [2][4][8][32][64] MFMA B image of weight_hh */
+  const float* lin_w[PA_MAX_LINEAR];          /* [out][in] as torch */
+  const float* lin_b[PA_MAX_LINEAR];
+  const float* cls_w;                         /* [num_classes][in] */
+  const float* cls_b;
+  const uint8_t* powerset_map;                /* [num_classes][num_speakers] 0/1 */
+} pa_seg_weights;
+
+/* frames per chunk for `num_samples` (SincNet.num_frames, models/blocks/sincnet.py:82-107) */
+int pa_seg_num_frames(int num_samples, int sinc_stride);
+size_t pa_seg_workspace_bytes(const pa_seg_weights* w, int num_chunks, int num_samples);
+/* Chunk b is wav[b*chunk_stride : b*chunk_stride + num_samples], zero beyond wav_len
+ * (Inference.slide's unfold + zero-padded last chunk, core/inference.py:261-278).
+ * logp: (num_chunks, F, num_classes) log-probabilities or NULL;
+ * multilabel: (num_chunks, F, num_speakers) uint8 {0,1} or NULL. */
+int pa_seg_forward(const pa_seg_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                   int num_chunks, int num_samples, float* logp, uint8_t* multilabel, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* building blocks of pa_seg_forward (exported for unit parity tests) */
+int pa_row_stats(const float* x, long row_stride, long total_len, int rows, int len, float eps,
+                 float* mean, float* rstd, void* stream);
+int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, int N, int stride,
+                     const float* mean, const float* rstd, float gamma, float beta,
+                     const float* filt_packed, float* out, void* stream);
+int pa_conv5_pool(const float* xin, int B, int cin, int Lin, const float* in_mean,
+                  const float* in_rstd, const float* gam, const float* bet, const float* w_packed,
+                  const float* bias64, float* out, void* stream);
+int pa_norm_transpose(const float* xin, int B, int T, const float* in_mean, const float* in_rstd,
+                      const float* gam, const float* bet, float* X0, void* stream);
+int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, long ldc,
+               int M, int N, int K, int act, int out_mode, void* stream);
+int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T,
+                void* stream);
+int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, const float* cw,
+                  const float* cb, int NC, const unsigned char* mapping, int S, float* logp,
+                  unsigned char* multilabel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYANNOTE_AMD_H */

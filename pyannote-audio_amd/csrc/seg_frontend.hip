@@ -1,0 +1,290 @@
+// SincNet front-end of PyanNet on gfx950 (reference: models/blocks/sincnet.py:163-184).
+//
+//   wav --InstanceNorm1d(1)--> sinc FIR(80x251, stride 10) --|.|--> maxpool3 --IN(80)+lrelu-->
+//       conv1d(80->60,k5) --> maxpool3 --IN(60)+lrelu--> conv1d(60->60,k5) --> maxpool3 --IN(60)+lrelu
+//
+// Kernel split (one launch each, all on the caller's stream):
+//   k_row_stats        two-pass mean / rstd of a row (waveform chunk or one (chunk,channel) row)
+//   k_sinc_fir_pool    normalise-on-load -> FIR as f32 MFMA GEMM -> |.| -> maxpool3   (un-normalised out)
+//   k_conv5_pool<CIN>  IN+lrelu-on-load  -> conv1d k=5 as f32 MFMA GEMM -> +bias -> maxpool3
+//   k_norm_transpose   IN+lrelu of the last stage, written as LSTM input rows [(tile,t,b16)][64]
+//
+// The max-pool over 3 consecutive conv positions is lane-local: MFMA row i of accumulator j
+// (j = 0,1,2) is mapped to conv position 3*i + j, so the three accumulators of a lane hold the
+// three members of one pooling window.
+#include "common.h"
+
+namespace pa {
+
+// ---------------------------------------------------------------------------------------------
+// Row statistics: mean and 1/sqrt(var_biased + eps) over `len` values; values beyond `valid`
+// (zero padding of the last chunk, inference.py:270-278) count as zeros.
+// grid = rows, block = 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, long row_stride,
+                                                    long total_len, int len, float eps,
+                                                    float* __restrict__ mean_out,
+                                                    float* __restrict__ rstd_out) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * row_stride;
+  long avail = total_len - base;  // number of real samples in this row
+  int valid = avail >= len ? len : (avail > 0 ? (int)avail : 0);
+  const float* row = x + base;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < valid; i += 256) s += row[i];
+  const float mean = block_sum<4>(s, red) / (float)len;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < valid; i += 256) {
+    float d = row[i] - mean;
+    q += d * d;
+  }
+  // zero-padded tail contributes (0 - mean)^2 each
+  float var = block_sum<4>(q, red);
+  var += (float)(len - valid) * mean * mean;
+  var /= (float)len;
+  if (threadIdx.x == 0) {
+    mean_out[blockIdx.x] = mean;
+    rstd_out[blockIdx.x] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sinc FIR + abs + maxpool3.
+//   grid = (ceil(P / PT), B), block = 320 (5 waves; wave w owns filters 16w..16w+15).
+//   filt : B-operand image [5][63][64] : filt[(w*63+kt)*64 + lane] = h[16w + (lane&15)][4kt + (lane>>4)]
+//          (tap 251 is zero padding).
+//   out  : (B, 80, P) un-normalised pooled magnitudes.
+// ---------------------------------------------------------------------------------------------
+constexpr int SINC_PT = 128;                       // pooled outputs per workgroup
+constexpr int SINC_XS = 30 * SINC_PT + 256;        // staged samples (>= 30*PT + 242)
+constexpr int SINC_OS = SINC_PT + 4;               // out-tile row stride in LDS
+
+__global__ __launch_bounds__(320) void k_sinc_fir_pool(
+    const float* __restrict__ wav, long wav_len, long chunk_stride, int N, int stride, int P,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float gamma, float beta,
+    const float* __restrict__ filt, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                // [SINC_XS]
+  float* os = smem + SINC_XS;      // [80][SINC_OS]
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * SINC_PT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  constexpr int STR = 10;          // SincNet stride (checked by the host wrapper)
+  constexpr int PS = 3 * STR;      // sample advance per pooled output
+
+  // stage normalised samples [PS*p0, PS*p0 + nstage)
+  const long cbase = (long)b * chunk_stride;
+  const float mu = mean[b], rs = rstd[b] * gamma;
+  for (int i = tid; i < SINC_XS; i += 320) {
+    const int sidx = PS * p0 + i;
+    float v = 0.f;
+    if (sidx < N) {
+      const long g = cbase + sidx;
+      const float raw = g < wav_len ? wav[g] : 0.f;
+      v = (raw - mu) * rs + beta;
+    }
+    xs[i] = v;
+  }
+  // filter taps -> registers (B operand)
+  float fb[63];
+#pragma unroll
+  for (int kt = 0; kt < 63; ++kt) fb[kt] = filt[(w * 63 + kt) * 64 + lane];
+  __syncthreads();
+
+  const int i16 = lane & 15, kq = lane >> 4;
+#pragma unroll 1
+  for (int grp = 0; grp < SINC_PT / 16; ++grp) {
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    const float* xp = xs + PS * (16 * grp + i16) + kq;
+#pragma unroll
+    for (int kt = 0; kt < 63; ++kt) {
+      a0 = MFMA16(xp[4 * kt], fb[kt], a0);
+      a1 = MFMA16(xp[4 * kt + STR], fb[kt], a1);
+      a2 = MFMA16(xp[4 * kt + 2 * STR], fb[kt], a2);
+    }
+    // lane holds filter 16w + i16 (column), pooled rows 16*grp + 4*kq + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = fmaxf(fmaxf(fabsf(a0[r]), fabsf(a1[r])), fabsf(a2[r]));
+      os[(16 * w + i16) * SINC_OS + 16 * grp + 4 * kq + r] = v;
+    }
+  }
+  __syncthreads();
+  const int np = min(SINC_PT, P - p0);
+  for (int i = tid; i < 80 * SINC_PT; i += 320) {
+    const int c = i / SINC_PT, p = i % SINC_PT;
+    if (p < np) out[((long)b * 80 + c) * P + p0 + p] = os[c * SINC_OS + p];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1d(k=5, stride 1) + bias + maxpool3 with InstanceNorm+leaky_relu applied to the input on load.
+//   grid = (ceil(P / PT), B), block = 256 (4 waves; wave w owns output channels 16w..16w+15, 60 real).
+//   wp : B-operand image [4][KT][64], K order k = tap*CIN + cin, KT = 5*CIN/4:
+//        wp[(w*KT+kt)*64 + lane] = W[16w + (lane&15)][cin][tap],  4kt + (lane>>4) = tap*CIN + cin
+//   xin: (B, CIN, Lin) un-normalised; in_mean/in_rstd: (B*CIN); gam/bet: (CIN)
+//   out: (B, 60, P) un-normalised pooled conv outputs.
+// ---------------------------------------------------------------------------------------------
+constexpr int CV_PT = 32;
+constexpr int CV_XW = 112;   // staged positions per channel row (>= 3*PT+4), 112 % 32 == 16: see DESIGN.md
+constexpr int CV_OS = CV_PT + 1;
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_conv5_pool(const float* __restrict__ xin, int Lin, int P,
+                                                     const float* __restrict__ in_mean,
+                                                     const float* __restrict__ in_rstd,
+                                                     const float* __restrict__ gam,
+                                                     const float* __restrict__ bet,
+                                                     const float* __restrict__ wp,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ out) {
+  constexpr int KT = 5 * CIN / 4;
+  constexpr int KPT = CIN / 4;  // k-steps per tap
+  __shared__ __attribute__((aligned(16))) float xs[CIN * CV_XW];
+  __shared__ float os[64 * CV_OS];
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * CV_PT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+  for (int i = tid; i < CIN * CV_XW; i += 256) {
+    const int c = i / CV_XW, q = i % CV_XW;
+    const int pos = 3 * p0 + q;
+    float v = 0.f;
+    if (q < 3 * CV_PT + 4 && pos < Lin) {
+      const int row = b * CIN + c;
+      v = (xin[(long)row * Lin + pos] - in_mean[row]) * (in_rstd[row] * gam[c]) + bet[c];
+      v = leaky_relu(v);
+    }
+    xs[i] = v;
+  }
+  float wb[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) wb[kt] = wp[(w * KT + kt) * 64 + lane];
+  __syncthreads();
+
+  const int i16 = lane & 15, kq = lane >> 4;
+  const float bv = bias[16 * w + i16];
+#pragma unroll 1
+  for (int grp = 0; grp < CV_PT / 16; ++grp) {
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    const float* xp = xs + kq * CV_XW + 3 * (16 * grp + i16);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int tap = kt / KPT, c4 = (kt % KPT) * 4;
+      const float* q = xp + c4 * CV_XW + tap;
+      a0 = MFMA16(q[0], wb[kt], a0);
+      a1 = MFMA16(q[1], wb[kt], a1);
+      a2 = MFMA16(q[2], wb[kt], a2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = fmaxf(fmaxf(a0[r], a1[r]), a2[r]) + bv;
+      os[(16 * w + i16) * CV_OS + 16 * grp + 4 * kq + r] = v;
+    }
+  }
+  __syncthreads();
+  const int np = min(CV_PT, P - p0);
+  for (int i = tid; i < 60 * CV_PT; i += 256) {
+    const int c = i / CV_PT, p = i % CV_PT;
+    if (p < np) out[((long)b * 60 + c) * P + p0 + p] = os[c * CV_OS + p];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Last InstanceNorm + leaky_relu, transposed into LSTM input rows:
+//   X0[((tile*T + t)*16 + b16)][64], b = 16*tile + b16, channels 60..63 and chunks b >= B are zero.
+// grid = (ceil(T/64), ntiles*16), block = 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_transpose(const float* __restrict__ xin, int B, int T,
+                                                         const float* __restrict__ in_mean,
+                                                         const float* __restrict__ in_rstd,
+                                                         const float* __restrict__ gam,
+                                                         const float* __restrict__ bet,
+                                                         float* __restrict__ X0) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int c = i >> 6, tt = i & 63;
+    float v = 0.f;
+    if (b < B && c < 60 && t0 + tt < T) {
+      const int row = b * 60 + c;
+      v = (xin[(long)row * T + t0 + tt] - in_mean[row]) * (in_rstd[row] * gam[c]) + bet[c];
+      v = leaky_relu(v);
+    }
+    tile[c][tt] = v;
+  }
+  __syncthreads();
+  const int bt = b >> 4, b16 = b & 15;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int tt = i >> 6, c = i & 63;
+    if (t0 + tt < T) X0[(((long)bt * T + t0 + tt) * 16 + b16) * 64 + c] = tile[c][tt];
+  }
+}
+
+}  // namespace pa
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int pa_row_stats(const float* x, long row_stride, long total_len, int rows, int len, float eps,
+                 float* mean, float* rstd, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(pa::k_row_stats, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, row_stride,
+                     total_len, len, eps, mean, rstd);
+  PA_CHECK_LAUNCH("pa_row_stats");
+  return 0;
+}
+
+int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, int N, int stride,
+                     const float* mean, const float* rstd, float gamma, float beta,
+                     const float* filt_packed, float* out, void* stream) {
+  PA_REQUIRE(stride == 10, "pa_sinc_fir_pool: only SincNet stride 10 is built (got %d)", stride);
+  const int L = (N - 251) / stride + 1;
+  const int P = L / 3;
+  if (B <= 0 || P <= 0) return 0;
+  const size_t lds = (pa::SINC_XS + 80 * pa::SINC_OS) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(pa::k_sinc_fir_pool, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(320), lds,
+                     (hipStream_t)stream, wav, wav_len, chunk_stride, N, stride, P, mean, rstd, gamma,
+                     beta, filt_packed, out);
+  PA_CHECK_LAUNCH("pa_sinc_fir_pool");
+  return 0;
+}
+
+int pa_conv5_pool(const float* xin, int B, int cin, int Lin, const float* in_mean,
+                  const float* in_rstd, const float* gam, const float* bet, const float* w_packed,
+                  const float* bias64, float* out, void* stream) {
+  const int P = (Lin - 4) / 3;
+  if (B <= 0 || P <= 0) return 0;
+  dim3 grid(pa::cdiv(P, pa::CV_PT), B);
+  if (cin == 80)
+    hipLaunchKernelGGL(pa::k_conv5_pool<80>, grid, dim3(256), 0, (hipStream_t)stream, xin, Lin, P,
+                       in_mean, in_rstd, gam, bet, w_packed, bias64, out);
+  else if (cin == 60)
+    hipLaunchKernelGGL(pa::k_conv5_pool<60>, grid, dim3(256), 0, (hipStream_t)stream, xin, Lin, P,
+                       in_mean, in_rstd, gam, bet, w_packed, bias64, out);
+  else
+    PA_REQUIRE(false, "pa_conv5_pool: unsupported cin %d", cin);
+  PA_CHECK_LAUNCH("pa_conv5_pool");
+  return 0;
+}
+
+int pa_norm_transpose(const float* xin, int B, int T, const float* in_mean, const float* in_rstd,
+                      const float* gam, const float* bet, float* X0, void* stream) {
+  if (B <= 0) return 0;
+  const int ntiles = (B + 15) / 16;
+  hipLaunchKernelGGL(pa::k_norm_transpose, dim3(pa::cdiv(T, 64), ntiles * 16), dim3(256), 0,
+                     (hipStream_t)stream, xin, B, T, in_mean, in_rstd, gam, bet, X0);
+  PA_CHECK_LAUNCH("pa_norm_transpose");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,333 @@
+// LSTM stack + feed-forward head of PyanNet on gfx950
+// (reference: models/segmentation/PyanNet.py:211-240; torch.nn.LSTM gate order i,f,g,o).
+//
+//   k_gemm_tn     C = act(A[M][K] * W[N][K]^T + bias)   f32 MFMA 32x32x2, 128x128x32 tiles.
+//                 Used for the LSTM input projections of ALL time steps at once, the two Linear
+//                 layers of the head and the embedding's seg_1 Linear.
+//   k_lstm_rec    the recurrence: one workgroup per (16-chunk tile, direction).  W_hh (128x512 fp32,
+//                 256 KB) lives in the register file of the CU for the whole sequence: 4 waves x 256
+//                 VGPRs as MFMA B operands; h_t goes through a double-buffered 16x128 LDS tile; the
+//                 cell state never leaves registers.  589 dependent steps, one barrier per step.
+//   k_classifier  Linear(K -> NC) + log-softmax + powerset arg-max -> multilabel LUT.
+//
+// Row order of all [m][*] activations in the LSTM stack: m = (tile*T + t)*16 + b16 (b = 16*tile+b16),
+// i.e. the 16 chunks of a tile are adjacent for a fixed time step, which is exactly the MFMA M
+// dimension of the recurrence.
+#include "common.h"
+
+namespace pa {
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  (TN: both operands K-contiguous)
+// ---------------------------------------------------------------------------------------------
+constexpr int GB = 128;      // BM = BN
+constexpr int GK = 32;       // BK
+constexpr int GLD = GK + 4;  // LDS row stride (floats): 9 x 16-B slots -> conflict-free b128 reads
+
+// out_mode 0: C[m*ldc + n]; out_mode 1 (LSTM gate pre-activations): C[((m>>4)*N + n)*16 + (m&15)]
+template <int ACT, int OUT_MODE>
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda,
+                                                  const float* __restrict__ W, int ldw,
+                                                  const float* __restrict__ bias,
+                                                  float* __restrict__ C, long ldc, int M, int N, int K,
+                                                  int nm, int nn) {
+  __shared__ __attribute__((aligned(16))) float As[GB * GLD];
+  __shared__ __attribute__((aligned(16))) float Ws[GB * GLD];
+  // block -> tile mapping; with 8 column tiles the 8 blocks sharing an A panel run on one XCD
+  int mt, nt;
+  const int bid = blockIdx.x;
+  if (nn == 8) {
+    nt = (bid >> 3) & 7;
+    mt = (bid & 7) + 8 * (bid >> 6);
+  } else {
+    nt = bid % nn;
+    mt = bid / nn;
+  }
+  if (mt >= nm) return;
+  const int m0 = mt * GB, n0 = nt * GB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;  // loader: row lr + 32*i, 4 floats at column lc
+
+  float4 ra[4], rw[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ar = m0 + lr + 32 * i, wr = n0 + lr + 32 * i;
+      ra[i] = ar < M ? *reinterpret_cast<const float4*>(A + (long)ar * lda + k0 + lc)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = wr < N ? *reinterpret_cast<const float4*>(W + (long)wr * ldw + k0 + lc)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(As + (lr + 32 * i) * GLD + lc) = ra[i];
+      *reinterpret_cast<float4*>(Ws + (lr + 32 * i) * GLD + lc) = rw[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fi = lane & 31, kh = lane >> 5;
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (k0 + GK < K) gload(k0 + GK);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      float4 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const float4*>(As + (64 * wm + 32 * i + fi) * GLD + kh * 16 + 4 * r4);
+        wf[i] = *reinterpret_cast<const float4*>(Ws + (64 * wn + 32 * i + fi) * GLD + kh * 16 + 4 * r4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = MFMA32(af[i].x, wf[j].x, acc[i][j]);
+          acc[i][j] = MFMA32(af[i].y, wf[j].y, acc[i][j]);
+          acc[i][j] = MFMA32(af[i].z, wf[j].z, acc[i][j]);
+          acc[i][j] = MFMA32(af[i].w, wf[j].w, acc[i][j]);
+        }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 64 * wn + 32 * j + fi;
+      const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + 64 * wm + 32 * i + 8 * q + 4 * kh;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * q + e] + bv;
+          if (ACT == 1) v[e] = leaky_relu(v[e]);
+        }
+        if (n < N) {
+          if (OUT_MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (m + e < M) C[(long)(m + e) * ldc + n] = v[e];
+          } else {
+            if (m < M)
+              *reinterpret_cast<float4*>(C + ((long)(m >> 4) * N + n) * 16 + (m & 15)) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM recurrence (hidden size 128).  grid = (ntiles, ndir), block = 256, 1 workgroup per CU.
+//   xproj : [tile][t][1024][16]  gate pre-activations x_t W_ih^T + b_ih + b_hh, column index
+//           dir*512 + w*128 + (q*2+s)*16 + n  <->  torch gate row q*128 + 32w + 16s + n   (q: i,f,g,o)
+//   whh_p : [dir][w][q*2+s][kt][lane]  =  W_hh[q*128 + 32w + 16s + (lane&15)][(lane>>4)*32 + kt]
+//   out   : [m][256], m = (tile*T + t)*16 + b16, columns dir*128 + j
+// ---------------------------------------------------------------------------------------------
+constexpr int LSTM_HS = 162;  // LDS row stride of h (floats); k index j lives at (j/32)*33 + j%32
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256, 1) void k_lstm_rec(const float* __restrict__ xproj,
+                                                      const float* __restrict__ whh_p,
+                                                      float* __restrict__ out, int T) {
+  __shared__ float hs[2 * 16 * LSTM_HS];
+  const int tile = blockIdx.x, dir = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+
+  float wr[8][32];
+  {
+    const float* wp = whh_p + (long)((dir * 4 + w) * 8 * 32) * 64 + lane;
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8)
+#pragma unroll
+      for (int kt = 0; kt < 32; ++kt) wr[q8][kt] = wp[(q8 * 32 + kt) * 64];
+  }
+  for (int i = tid; i < 2 * 16 * LSTM_HS; i += 256) hs[i] = 0.f;
+  float c[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[s][r] = 0.f;
+  __syncthreads();
+
+  const float* xbase = xproj + ((long)tile * T * 1024 + dir * 512 + w * 128 + n) * 16 + 4 * g;
+  float* obase = out + ((long)tile * T * 16 + 4 * g) * 256 + dir * 128 + 32 * w + n;
+
+  f32x4 xin[8];
+  {
+    const int t = dir ? T - 1 : 0;
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8)
+      xin[q8] = *reinterpret_cast<const f32x4*>(xbase + ((long)t * 1024 + q8 * 16) * 16);
+  }
+  int cur = 0;
+#pragma unroll 1
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+    f32x4 acc[8];
+#pragma unroll
+    for (int q8 = 0; q8 < 8; ++q8) acc[q8] = xin[q8];
+    if (step + 1 < T) {
+      const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8)
+        xin[q8] = *reinterpret_cast<const f32x4*>(xbase + ((long)tn * 1024 + q8 * 16) * 16);
+    }
+    const float* hp = hs + (cur * 16 + n) * LSTM_HS + g * 33;
+    float a[32];
+#pragma unroll
+    for (int kt = 0; kt < 32; ++kt) a[kt] = hp[kt];
+#pragma unroll
+    for (int kt = 0; kt < 32; ++kt)
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) acc[q8] = MFMA16(a[kt], wr[q8][kt], acc[q8]);
+
+    float* hn = hs + ((cur ^ 1) * 16 + 4 * g) * LSTM_HS + w * 33 + n;
+    float* op = obase + (long)t * 16 * 256;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = sigmoidf_(acc[0 + s][r]);
+        const float fg = sigmoidf_(acc[2 + s][r]);
+        const float gg = tanhf(acc[4 + s][r]);
+        const float og = sigmoidf_(acc[6 + s][r]);
+        const float cn = fg * c[s][r] + ig * gg;
+        c[s][r] = cn;
+        const float h = og * tanhf(cn);
+        hn[r * LSTM_HS + 16 * s] = h;
+        op[r * 256 + 16 * s] = h;
+      }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// classifier Linear(K -> NC) + log-softmax + hard powerset -> multilabel
+// (PyanNet.py:240, core/model.py:290-291, utils/powerset.py:115-140).  One thread per row.
+// ---------------------------------------------------------------------------------------------
+constexpr int CLS_MAXC = 16;
+
+__global__ __launch_bounds__(256) void k_classifier(const float* __restrict__ X, int ldx, int K, int M,
+                                                     int T, int B, const float* __restrict__ cw,
+                                                     const float* __restrict__ cb, int NC,
+                                                     const unsigned char* __restrict__ mapping, int S,
+                                                     float* __restrict__ logp,
+                                                     unsigned char* __restrict__ ml) {
+  extern __shared__ float wsh[];  // [NC][K] + [NC]
+  for (int i = threadIdx.x; i < NC * K; i += 256) wsh[i] = cw[i];
+  for (int i = threadIdx.x; i < NC; i += 256) wsh[NC * K + i] = cb[i];
+  __syncthreads();
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int b16 = (int)(m & 15);
+  const long tt = m >> 4;
+  const int t = (int)(tt % T), tile = (int)(tt / T);
+  const int b = tile * 16 + b16;
+  if (b >= B) return;
+  float z[CLS_MAXC];
+#pragma unroll
+  for (int cidx = 0; cidx < CLS_MAXC; ++cidx) z[cidx] = cidx < NC ? wsh[NC * K + cidx] : 0.f;
+  const float* x = X + m * ldx;
+  for (int k = 0; k < K; k += 4) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + k);
+#pragma unroll
+    for (int cidx = 0; cidx < CLS_MAXC; ++cidx)
+      if (cidx < NC) {
+        const float* wrow = wsh + cidx * K + k;
+        z[cidx] = fmaf(xv.x, wrow[0], z[cidx]);
+        z[cidx] = fmaf(xv.y, wrow[1], z[cidx]);
+        z[cidx] = fmaf(xv.z, wrow[2], z[cidx]);
+        z[cidx] = fmaf(xv.w, wrow[3], z[cidx]);
+      }
+  }
+  float mx = z[0];
+  int am = 0;
+#pragma unroll
+  for (int cidx = 1; cidx < CLS_MAXC; ++cidx)
+    if (cidx < NC && z[cidx] > mx) {
+      mx = z[cidx];
+      am = cidx;
+    }
+  float se = 0.f;
+#pragma unroll
+  for (int cidx = 0; cidx < CLS_MAXC; ++cidx)
+    if (cidx < NC) se += expf(z[cidx] - mx);
+  const float lse = mx + logf(se);
+  const long o = (long)b * T + t;
+  if (logp != nullptr)
+    for (int cidx = 0; cidx < NC; ++cidx) logp[o * NC + cidx] = z[cidx] - lse;
+  if (ml != nullptr)
+    for (int s = 0; s < S; ++s) ml[o * S + s] = mapping[am * S + s];
+}
+
+}  // namespace pa
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, long ldc,
+               int M, int N, int K, int act, int out_mode, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  PA_REQUIRE(K % pa::GK == 0 && lda % 4 == 0 && ldw % 4 == 0,
+             "pa_gemm_tn: K (%d) must be a multiple of 32 and lda/ldw multiples of 4", K);
+  PA_REQUIRE(out_mode == 0 || (M % 16 == 0), "pa_gemm_tn: out_mode 1 needs M %% 16 == 0");
+  const int nm = pa::cdiv(M, pa::GB), nn = pa::cdiv(N, pa::GB);
+  const int grid = nn == 8 ? pa::cdiv(nm, 8) * 64 : nm * nn;
+  hipStream_t st = (hipStream_t)stream;
+#define PA_GEMM(ACT, OM)                                                                          \
+  hipLaunchKernelGGL((pa::k_gemm_tn<ACT, OM>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, \
+                     C, ldc, M, N, K, nm, nn)
+  if (act == 0 && out_mode == 0) PA_GEMM(0, 0);
+  else if (act == 1 && out_mode == 0) PA_GEMM(1, 0);
+  else if (act == 0 && out_mode == 1) PA_GEMM(0, 1);
+  else PA_REQUIRE(false, "pa_gemm_tn: unsupported act/out_mode %d/%d", act, out_mode);
+#undef PA_GEMM
+  PA_CHECK_LAUNCH("pa_gemm_tn");
+  return 0;
+}
+
+int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T,
+                void* stream) {
+  if (ntiles <= 0 || T <= 0) return 0;
+  hipLaunchKernelGGL(pa::k_lstm_rec, dim3(ntiles, ndir), dim3(256), 0, (hipStream_t)stream, xproj,
+                     whh_packed, out, T);
+  PA_CHECK_LAUNCH("pa_lstm_rec");
+  return 0;
+}
+
+int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, const float* cw,
+                  const float* cb, int NC, const unsigned char* mapping, int S, float* logp,
+                  unsigned char* multilabel, void* stream) {
+  PA_REQUIRE(NC <= pa::CLS_MAXC && K % 4 == 0, "pa_classifier: NC <= 16 and K %% 4 == 0 required");
+  const long M = (long)ntiles * T * 16;
+  if (M <= 0) return 0;
+  const size_t lds = (size_t)(NC * K + NC) * sizeof(float);
+  hipLaunchKernelGGL(pa::k_classifier, dim3(pa::cdiv(M, 256)), dim3(256), lds, (hipStream_t)stream, X,
+                     ldx, K, (int)M, T, B, cw, cb, NC, mapping, S, logp, multilabel);
+  PA_CHECK_LAUNCH("pa_classifier");
+  return 0;
+}
+
+}  // extern "C"

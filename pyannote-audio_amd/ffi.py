@@ -1,0 +1,123 @@
+"""ctypes binding of libpyannote_amd.so (C ABI: include/pyannote_amd.h).
+
+PyTorch-ROCm is used for device memory and streams only: tensors go in as raw device pointers,
+kernels are launched on torch's current HIP stream.  There is NO fallback: if the library (or a GPU)
+is missing, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_LIB = None
+PA_MAX_LSTM_LAYERS = 8
+PA_MAX_LINEAR = 4
+
+c_fp = C.c_void_p  # device pointers travel as void*
+
+
+class SegWeights(C.Structure):
+    _fields_ = [
+        ("sinc_stride", C.c_int32), ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32),
+        ("lstm_bidir", C.c_int32), ("num_linear", C.c_int32), ("linear_hidden", C.c_int32),
+        ("num_classes", C.c_int32), ("num_speakers", C.c_int32),
+        ("wav_gamma", C.c_float), ("wav_beta", C.c_float),
+        ("sinc_filt", c_fp), ("norm0", c_fp), ("conv1_w", c_fp), ("conv1_b", c_fp), ("norm1", c_fp),
+        ("conv2_w", c_fp), ("conv2_b", c_fp), ("norm2", c_fp),
+        ("lstm_wih", c_fp * PA_MAX_LSTM_LAYERS), ("lstm_bias", c_fp * PA_MAX_LSTM_LAYERS),
+        ("lstm_whh", c_fp * PA_MAX_LSTM_LAYERS),
+        ("lin_w", c_fp * PA_MAX_LINEAR), ("lin_b", c_fp * PA_MAX_LINEAR),
+        ("cls_w", c_fp), ("cls_b", c_fp), ("powerset_map", c_fp),
+    ]
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return Path(__file__).resolve().parent / "libpyannote_amd.so"
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises LibraryNotBuilt if the .so is absent --
+    the product never silently degrades to a CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not p.exists():
+        raise LibraryNotBuilt(
+            f"{p} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    lib.pa_last_error.restype = C.c_char_p
+    lib.pa_version.restype = C.c_int
+    lib.pa_seg_workspace_bytes.restype = C.c_size_t
+    lib.pa_seg_workspace_bytes.argtypes = [C.POINTER(SegWeights), C.c_int, C.c_int]
+    lib.pa_seg_num_frames.argtypes = [C.c_int, C.c_int]
+    lib.pa_seg_forward.argtypes = [C.POINTER(SegWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                   c_fp, c_fp, c_fp, C.c_size_t, c_fp]
+    lib.pa_row_stats.argtypes = [c_fp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp]
+    lib.pa_sinc_fir_pool.argtypes = [c_fp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, c_fp, c_fp,
+                                     C.c_float, C.c_float, c_fp, c_fp, c_fp]
+    lib.pa_conv5_pool.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                  c_fp, c_fp]
+    lib.pa_norm_transpose.argtypes = [c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+    lib.pa_gemm_tn.argtypes = [c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, c_fp]
+    lib.pa_lstm_rec.argtypes = [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]
+    lib.pa_classifier.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp,
+                                  C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]
+    _declare_optional(lib)
+    _LIB = lib
+    return lib
+
+
+# (name, argtypes, restype) of entry points added by later kernel files; declared when present so
+# that a partially built library fails at call time with a clear message rather than at import.
+_OPTIONAL: list[tuple] = []
+
+
+def _declare_optional(lib):
+    for name, argtypes, restype in _OPTIONAL:
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            if restype is not None:
+                fn.restype = restype
+
+
+def ptr(t: torch.Tensor | None):
+    """Raw device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libpyannote_amd kernels need device tensors (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise RuntimeError("libpyannote_amd kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc: int, what: str = ""):
+    if rc == 0:
+        return
+    msg = load().pa_last_error().decode()
+    if rc == 2:
+        raise MemoryError(f"{what}: {msg}")
+    if rc == 3:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("pyannote_audio_amd needs an AMD GPU (gfx950): torch.cuda.is_available() "
+                           "is False and there is no CPU fallback")
+    load()

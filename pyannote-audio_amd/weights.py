@@ -1,0 +1,165 @@
+"""Weight pre-packing: reference state-dict layout -> device images the gfx950 kernels read.
+
+Done once at model load on the host (torch CPU index ops), then uploaded; the per-call path never
+touches these again.  Layouts are documented in include/pyannote_amd.h and DESIGN.md.
+
+State-dict layout accepted (core/model.py:244-262):
+  PyanNet : sincnet.wav_norm1d.*, sincnet.conv1d.0.filterbank.{low_hz_,band_hz_},
+            sincnet.conv1d.{1,2}.*, sincnet.norm1d.{0,1,2}.*, lstm.* (monolithic or ModuleList),
+            linear.{i}.*, classifier.*
+"""
+from __future__ import annotations
+
+import ctypes as C
+from itertools import combinations
+
+import numpy as np
+import torch
+
+from . import ffi
+
+
+# ---------------------------------------------------------------------------------------------
+# ParamSincFB filter synthesis (asteroid_filterbanks 0.4.0 `ParamSincFB.filters`, third party:
+# restated from the published algorithm; models/blocks/sincnet.py:58-69 is the call site)
+# ---------------------------------------------------------------------------------------------
+def sinc_filters(low_hz_: torch.Tensor, band_hz_: torch.Tensor, kernel_size: int = 251,
+                 sample_rate: float = 16000.0, min_low_hz: float = 50, min_band_hz: float = 50
+                 ) -> torch.Tensor:
+    """(n_filters/2, 1) x2 learnable scalars -> (n_filters, kernel_size) fp32 taps: first the
+    cosine-phase (even) filters, then the sine-phase (odd) ones."""
+    low_hz_ = low_hz_.detach().float().cpu().view(-1, 1)
+    band_hz_ = band_hz_.detach().float().cpu().view(-1, 1)
+    half = kernel_size // 2
+    window = torch.from_numpy(np.hamming(kernel_size)[:half]).float()
+    n = 2 * np.pi * (torch.arange(-half, 0.0).view(1, -1) / float(sample_rate))
+    low = min_low_hz + torch.abs(low_hz_)
+    high = torch.clamp(low + min_band_hz + torch.abs(band_hz_), min_low_hz, float(sample_rate) / 2)
+    band = (high - low)[:, 0]
+    ft_low, ft_high = torch.matmul(low, n), torch.matmul(high, n)
+    cos_left = ((torch.sin(ft_high) - torch.sin(ft_low)) / (n / 2)) * window
+    cos = torch.cat([cos_left, 2 * band.view(-1, 1), torch.flip(cos_left, dims=[1])], dim=1)
+    sin_left = ((torch.cos(ft_low) - torch.cos(ft_high)) / (n / 2)) * window
+    sin = torch.cat([sin_left, torch.zeros_like(band.view(-1, 1)), -torch.flip(sin_left, dims=[1])],
+                    dim=1)
+    cos = cos / (2 * band[:, None])
+    sin = sin / (2 * band[:, None])
+    return torch.cat([cos, sin], dim=0).contiguous()
+
+
+def powerset_mapping(num_classes: int, max_set_size: int) -> torch.Tensor:
+    """utils/powerset.py:80-109: rows = powerset classes in `combinations` order."""
+    rows = []
+    for size in range(0, max_set_size + 1):
+        for cs in combinations(range(num_classes), size):
+            r = [0] * num_classes
+            for c in cs:
+                r[c] = 1
+            rows.append(r)
+    return torch.tensor(rows, dtype=torch.uint8)
+
+
+def _mfma_b_image(wk: torch.Tensor, n_tiles: int) -> torch.Tensor:
+    """wk: (16*n_tiles, K) with K % 4 == 0 -> [tile][kt][lane] where lane = kq*16 + n holds
+    wk[16*tile + n][4*kt + kq] (the B operand of v_mfma_f32_16x16x4_f32)."""
+    n16, K = wk.shape
+    assert n16 == 16 * n_tiles and K % 4 == 0
+    return wk.view(n_tiles, 16, K // 4, 4).permute(0, 2, 3, 1).contiguous().view(-1)
+
+
+def _lstm_row_perm() -> torch.Tensor:
+    """perm[col'] = torch gate row, col' = w*128 + (q*2+s)*16 + n  <->  q*128 + 32w + 16s + n."""
+    perm = torch.empty(512, dtype=torch.long)
+    for w in range(4):
+        for q in range(4):
+            for s in range(2):
+                for n in range(16):
+                    perm[w * 128 + (q * 2 + s) * 16 + n] = q * 128 + 32 * w + 16 * s + n
+    return perm
+
+
+def _lstm_whh_image(whh: torch.Tensor) -> torch.Tensor:
+    """(512,128) weight_hh -> [w][q8][kt][lane]: W[q*128+32w+16s+(lane&15)][(lane>>4)*32+kt]."""
+    w_ = torch.arange(4).view(4, 1, 1, 1, 1)
+    q8 = torch.arange(8).view(1, 8, 1, 1, 1)
+    kt = torch.arange(32).view(1, 1, 32, 1, 1)
+    kq = torch.arange(4).view(1, 1, 1, 4, 1)
+    n = torch.arange(16).view(1, 1, 1, 1, 16)
+    rows = (q8 // 2) * 128 + 32 * w_ + 16 * (q8 % 2) + n
+    cols = kq * 32 + kt
+    rows, cols = torch.broadcast_tensors(rows, cols)
+    return whh[rows, cols].contiguous().view(-1)
+
+
+class SegmentationPack:
+    """Device-resident, kernel-ready PyanNet weights + the `pa_seg_weights` struct."""
+
+    def __init__(self, state_dict: dict, hparams: dict, num_classes: int, num_speakers: int,
+                 max_set_size: int, device: torch.device):
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+        sinc = {"stride": 10, **(hparams.get("sincnet") or {})}
+        lstm = {"hidden_size": 128, "num_layers": 2, "bidirectional": True, "monolithic": True,
+                **(hparams.get("lstm") or {})}
+        linear = {"hidden_size": 128, "num_layers": 2, **(hparams.get("linear") or {})}
+        if sinc["stride"] != 10 or lstm["hidden_size"] != 128 or not lstm["bidirectional"]:
+            raise NotImplementedError("kernels are built for SincNet stride 10 and bi-LSTM(128)")
+        if linear["num_layers"] > 0 and linear["hidden_size"] != 128:
+            raise NotImplementedError("kernels are built for Linear(128) heads")
+        self.device = device
+        self._keep: list[torch.Tensor] = []
+        w = ffi.SegWeights()
+        w.sinc_stride = 10
+        w.lstm_layers = L = int(lstm["num_layers"])
+        w.lstm_hidden, w.lstm_bidir = 128, 1
+        w.num_linear, w.linear_hidden = int(linear["num_layers"]), 128
+        w.num_classes, w.num_speakers = num_classes, num_speakers
+        w.wav_gamma = float(sd["sincnet.wav_norm1d.weight"][0])
+        w.wav_beta = float(sd["sincnet.wav_norm1d.bias"][0])
+
+        taps = sinc_filters(sd["sincnet.conv1d.0.filterbank.low_hz_"],
+                            sd["sincnet.conv1d.0.filterbank.band_hz_"])
+        self.sinc_taps = taps  # (80, 251) kept for tests
+        w.sinc_filt = self._up(_mfma_b_image(torch.nn.functional.pad(taps, (0, 1)), 5))
+        for i, c in enumerate((80, 60, 60)):
+            nb = torch.cat([sd[f"sincnet.norm1d.{i}.weight"], sd[f"sincnet.norm1d.{i}.bias"]])
+            setattr(w, f"norm{i}", self._up(nb))
+        for i, cin in ((1, 80), (2, 60)):
+            cw = sd[f"sincnet.conv1d.{i}.weight"]  # (60, cin, 5)
+            wk = torch.zeros(64, 5 * cin)
+            wk[:60] = cw.permute(0, 2, 1).reshape(60, 5 * cin)  # k = tap*cin + c
+            setattr(w, f"conv{i}_w", self._up(_mfma_b_image(wk, 4)))
+            cb = torch.zeros(64)
+            cb[:60] = sd[f"sincnet.conv1d.{i}.bias"]
+            setattr(w, f"conv{i}_b", self._up(cb))
+
+        perm = _lstm_row_perm()
+        for l in range(L):
+            if lstm["monolithic"]:
+                key = lambda name, rev: f"lstm.{name}_l{l}" + ("_reverse" if rev else "")
+            else:
+                key = lambda name, rev: f"lstm.{l}.{name}_l0" + ("_reverse" if rev else "")
+            wih, bias, whh = [], [], []
+            for rev in (False, True):
+                wi = sd[key("weight_ih", rev)][perm]
+                if wi.shape[1] == 60:
+                    wi = torch.nn.functional.pad(wi, (0, 4))
+                wih.append(wi)
+                bias.append((sd[key("bias_ih", rev)] + sd[key("bias_hh", rev)])[perm])
+                whh.append(_lstm_whh_image(sd[key("weight_hh", rev)]))
+            w.lstm_wih[l] = self._up(torch.cat(wih, 0)).value
+            w.lstm_bias[l] = self._up(torch.cat(bias, 0)).value
+            w.lstm_whh[l] = self._up(torch.cat(whh, 0)).value
+        for l in range(w.num_linear):
+            w.lin_w[l] = self._up(sd[f"linear.{l}.weight"]).value
+            w.lin_b[l] = self._up(sd[f"linear.{l}.bias"]).value
+        w.cls_w = self._up(sd["classifier.weight"])
+        w.cls_b = self._up(sd["classifier.bias"])
+        self.mapping = powerset_mapping(num_speakers, max_set_size)
+        assert self.mapping.shape[0] == num_classes
+        w.powerset_map = self._up(self.mapping)
+        self.struct = w
+
+    def _up(self, t: torch.Tensor):
+        d = t.contiguous().to(self.device)
+        self._keep.append(d)
+        return C.c_void_p(d.data_ptr())
