@@ -96,6 +96,66 @@ int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, cons
                   const float* cb, int NC, const unsigned char* mapping, int S, float* logp,
                   unsigned char* multilabel, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Embedding model: replaces WeSpeakerResNet34.forward (models/embedding/wespeaker/__init__.py:
+ * 324-343: compute_fbank :113-139 -> ResNet.forward resnet.py:399-430 -> TSTP/StatsPool
+ * resnet.py:49-66, blocks/pooling.py:30-130 -> seg_1) as called from
+ * PyannoteAudioPretrainedSpeakerEmbedding.__call__ (pipelines/speaker_verification.py:704-716).
+ * The backbone runs once per chunk and is pooled for all S masks (forward_frames /
+ * forward_embedding split, wespeaker/__init__.py:288-322).
+ * ---------------------------------------------------------------------------------------- */
+#define PA_MAX_RES_BLOCKS 64
+
+typedef struct pa_emb_weights {
+  int32_t num_mel;       /* 80 */
+  int32_t embed_dim;     /* 256 */
+  int32_t num_layers;    /* 4 */
+  int32_t num_blocks[4]; /* 3,4,6,3 */
+  int32_t planes[4];     /* 32,64,128,256 */
+  /* fbank tables */
+  const float* fb_window;   /* [400] hamming (periodic=False) */
+  const float* fb_tw256;    /* [256][2] exp(-2 pi i m/256) */
+  const float* fb_tw512;    /* [257][2] exp(-2 pi i k/512) */
+  const float* fb_mel_w;    /* [num_mel][257] */
+  const int32_t* fb_mel_lo; /* [num_mel] first / last FFT bin with non-zero weight */
+  const int32_t* fb_mel_hi;
+  /* BatchNorm folded: w *= gamma/sqrt(var+eps), shift = beta - mean*gamma/sqrt(var+eps) */
+  const float* stem_w;     /* [9][32]  (tap = 3*dmel + dtime) */
+  const float* stem_shift; /* [32] */
+  const float* blk_w1[PA_MAX_RES_BLOCKS];     /* [9][cout][cin] */
+  const float* blk_shift1[PA_MAX_RES_BLOCKS]; /* [cout] */
+  const float* blk_w2[PA_MAX_RES_BLOCKS];     /* [9][cout][cout] */
+  const float* blk_shift2[PA_MAX_RES_BLOCKS];
+  const float* blk_wsc[PA_MAX_RES_BLOCKS];    /* [cout][cin] 1x1 stride-2 shortcut or NULL */
+  const float* blk_shiftsc[PA_MAX_RES_BLOCKS];
+  const float* seg1_w; /* [embed_dim][2 * planes[3] * num_mel/8] */
+  const float* seg1_b;
+} pa_emb_weights;
+
+/* fbank frames for num_samples (25 ms / 10 ms, snip_edges) and frames after the 3 stride-2 stages */
+int pa_emb_num_fbank_frames(int num_samples);
+int pa_emb_num_pool_frames(const pa_emb_weights* w, int num_samples);
+size_t pa_emb_workspace_bytes(const pa_emb_weights* w, int num_chunks, int num_samples, int num_masks);
+/* chunk b = wav[b*chunk_stride : +num_samples] (zero past wav_len);
+ * masks: (num_chunks, S, mask_frames) fp32 or NULL (S = 1, unweighted);
+ * nearest_idx: (pool_frames) int32 source index of F.interpolate(mode="nearest"), ignored if !masks;
+ * emb: (num_chunks, S, embed_dim). */
+int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                   int num_chunks, int num_samples, const float* masks, int num_masks, int mask_frames,
+                   const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+int pa_fbank(const float* wav, long wav_len, long chunk_stride, int B, int N, const float* window,
+             const float* tw256, const float* tw512, const float* mel_w, const int* mel_lo,
+             const int* mel_hi, int nmel, float* out, int center, void* stream);
+int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, const float* shift,
+                   float* out, void* stream);
+int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, const float* shift,
+               const float* R, float* Y, int cout, int stride, int relu, void* stream);
+int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream);
+int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
+                  const int* nearest_idx, float* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,153 @@
+// pa_emb_forward: fbank -> ResNet34 -> weighted stats pooling -> Linear, sequenced on one stream.
+// Replaces WeSpeakerResNet34.forward (wespeaker/__init__.py:324-343, resnet.py:399-430).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pyannote_amd.h"
+
+namespace pa {
+void set_error(const char* fmt, ...);
+}
+
+namespace {
+
+struct EmbPlan {
+  int B, N, T, F, S;
+  int Hs[5], Ws[5];  // spatial dims after stem (index 0) and after each layer
+  size_t fbank, act[3], stats, total, act_elems;
+};
+inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p) {
+  if (N < 400) return false;
+  p->B = B;
+  p->N = N;
+  p->S = S < 1 ? 1 : S;
+  p->T = 1 + (N - 400) / 160;
+  p->F = w->num_mel;
+  p->Hs[0] = p->F;
+  p->Ws[0] = p->T;
+  for (int l = 0; l < w->num_layers; ++l) {
+    const int s = l == 0 ? 1 : 2;
+    p->Hs[l + 1] = (p->Hs[l] - 1) / s + 1;
+    p->Ws[l + 1] = (p->Ws[l] - 1) / s + 1;
+  }
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += align64(n);
+    return r;
+  };
+  p->fbank = take((size_t)B * p->T * p->F);
+  p->act_elems = (size_t)B * p->Hs[0] * p->Ws[0] * w->planes[0];
+  for (int i = 0; i < 3; ++i) p->act[i] = take(p->act_elems);
+  const int L = w->num_layers;
+  p->stats = take((size_t)B * p->S * 2 * w->planes[L - 1] * p->Hs[L]);
+  p->total = o;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_emb_num_fbank_frames(int num_samples) {
+  return num_samples < 400 ? 0 : 1 + (num_samples - 400) / 160;
+}
+
+int pa_emb_num_pool_frames(const pa_emb_weights* w, int num_samples) {
+  EmbPlan p;
+  if (!make_plan(w, 1, num_samples, 1, &p)) return 0;
+  return p.Ws[w->num_layers];
+}
+
+size_t pa_emb_workspace_bytes(const pa_emb_weights* w, int num_chunks, int num_samples, int num_masks) {
+  EmbPlan p;
+  if (!make_plan(w, num_chunks, num_samples, num_masks, &p)) return 0;
+  return p.total * sizeof(float);
+}
+
+int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                   int num_chunks, int num_samples, const float* masks, int num_masks, int mask_frames,
+                   const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+  if (num_chunks <= 0) return 0;
+  EmbPlan p;
+  if (w->num_layers != 4 || !make_plan(w, num_chunks, num_samples, masks ? num_masks : 1, &p)) {
+    pa::set_error("pa_emb_forward: %d samples is too short (fbank needs >= 400) or bad layer count",
+                  num_samples);
+    return 3;
+  }
+  if (workspace_bytes < p.total * sizeof(float)) {
+    pa::set_error("pa_emb_forward: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                  p.total * sizeof(float));
+    return 3;
+  }
+  float* ws = (float*)workspace;
+  const int B = p.B;
+  int rc;
+#define RUN(call)           \
+  do {                      \
+    rc = (call);            \
+    if (rc != 0) return rc; \
+  } while (0)
+
+  RUN(pa_fbank(wav, wav_len, chunk_stride, B, p.N, w->fb_window, w->fb_tw256, w->fb_tw512, w->fb_mel_w,
+               w->fb_mel_lo, w->fb_mel_hi, w->num_mel, ws + p.fbank, 1, stream));
+  float* cur = ws + p.act[0];
+  float* f1 = ws + p.act[1];
+  float* f2 = ws + p.act[2];
+  RUN(pa_resnet_stem(ws + p.fbank, B, p.T, p.F, w->stem_w, w->stem_shift, cur, stream));
+
+  int blk = 0;
+  int cin = w->planes[0];
+  for (int l = 0; l < w->num_layers; ++l) {
+    const int cout = w->planes[l];
+    for (int i = 0; i < w->num_blocks[l]; ++i, ++blk) {
+      if (blk >= PA_MAX_RES_BLOCKS) {
+        pa::set_error("pa_emb_forward: more than %d residual blocks", PA_MAX_RES_BLOCKS);
+        return 3;
+      }
+      const int stride = (i == 0 && l > 0) ? 2 : 1;
+      const int H = stride == 2 ? p.Hs[l] : p.Hs[l + 1], W = stride == 2 ? p.Ws[l] : p.Ws[l + 1];
+      const int Ho = p.Hs[l + 1], Wo = p.Ws[l + 1];
+      if (w->blk_wsc[blk] != nullptr) {
+        // out = relu(bn2(conv2(relu(bn1(conv1_s(x))))) + bn_sc(conv1x1_s(x)))   (resnet.py:140-145)
+        RUN(pa_conv3x3(cur, B, H, W, cin, w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1, cout, stride,
+                       1, stream));
+        const size_t q = (size_t)B * Ho * Wo * cin;
+        float* G = f2;
+        float* R = f2 + ((q + 63) & ~(size_t)63);
+        RUN(pa_gather_s2(cur, B, H, W, cin, G, stream));
+        RUN(pa_gemm_tn(G, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, B * Ho * Wo, cout, cin,
+                       0, 0, stream));
+        RUN(pa_conv3x3(f1, B, Ho, Wo, cout, w->blk_w2[blk], w->blk_shift2[blk], R, cur, cout, 1, 1,
+                       stream));
+      } else {
+        if (stride != 1 || cin != cout) {
+          pa::set_error("pa_emb_forward: block %d needs a shortcut conv but none was given", blk);
+          return 3;
+        }
+        RUN(pa_conv3x3(cur, B, H, W, cin, w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1, 1,
+                       stream));
+        RUN(pa_conv3x3(f1, B, H, W, cout, w->blk_w2[blk], w->blk_shift2[blk], cur, f2, cout, 1, 1,
+                       stream));
+        float* t = cur;
+        cur = f2;
+        f2 = t;
+      }
+      cin = cout;
+    }
+  }
+  const int L = w->num_layers;
+  const int S = p.S;
+  RUN(pa_stats_pool(cur, B, p.Hs[L], p.Ws[L], w->planes[L - 1], masks, S, mask_frames, nearest_idx,
+                    ws + p.stats, stream));
+  const int D2 = 2 * w->planes[L - 1] * p.Hs[L];
+  RUN(pa_gemm_tn(ws + p.stats, D2, w->seg1_w, D2, w->seg1_b, emb, w->embed_dim, B * S, w->embed_dim, D2,
+                 0, 0, stream));
+#undef RUN
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Weighted temporal statistics pooling (TSTP) on gfx950
+// (reference: models/embedding/wespeaker/resnet.py:49-66 + models/blocks/pooling.py:30-61, 76-130).
+//
+// Input  feat[b][f][t][c]   (NHWC output of layer4: f = 10 mel rows, t = T' frames, c = 256)
+// Masks  w[b][s][Fm]        per (chunk, local speaker) frame weights at the segmentation resolution;
+//                           resized to T' with F.interpolate(mode="nearest") = idx[t] (host-computed
+//                           with torch's float formula floor(t * (float)Fm / T'))
+// Output stats[b][s][2*D]   D = c*10 + f (TSTP's channel-major flattening): mean | std
+//   v1 = sum w + 1e-8 ; mean = sum(x w)/v1 ; var = sum((x-mean)^2 w) / (v1 - sum(w^2)/v1 + 1e-8)
+// The backbone runs ONCE per chunk and is pooled for all S speakers here (the reference runs the whole
+// network once per (chunk, speaker), pipelines/speaker_diarization.py:417-425).
+#include "common.h"
+
+namespace pa {
+
+constexpr int POOL_MAXS = 4;
+constexpr int POOL_MAXT = 512;
+
+__global__ __launch_bounds__(256) void k_stats_pool(const float* __restrict__ feat, int Fh, int Tp,
+                                                    int Cc, const float* __restrict__ masks, int S,
+                                                    int Fm, const int* __restrict__ idx,
+                                                    float* __restrict__ stats) {
+  __shared__ float ws[POOL_MAXS][POOL_MAXT];
+  __shared__ float v1s[POOL_MAXS], dens[POOL_MAXS];
+  const int b = blockIdx.z, f = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < S * Tp; i += 256) {
+    const int s = i / Tp, t = i % Tp;
+    ws[s][t] = masks != nullptr ? masks[((long)b * S + s) * Fm + idx[t]] : 1.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < S) {
+    const int s = threadIdx.x;
+    float a = 0.f, q = 0.f;
+    for (int t = 0; t < Tp; ++t) {
+      a += ws[s][t];
+      q += ws[s][t] * ws[s][t];
+    }
+    const float v1 = a + 1e-8f;
+    v1s[s] = v1;
+    dens[s] = v1 - q / v1 + 1e-8f;
+  }
+  __syncthreads();
+  if (c >= Cc) return;
+  const float* x = feat + (((long)b * Fh + f) * Tp) * Cc + c;
+  float m[POOL_MAXS];
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s) m[s] = 0.f;
+  for (int t = 0; t < Tp; ++t) {
+    const float xv = x[(long)t * Cc];
+#pragma unroll
+    for (int s = 0; s < POOL_MAXS; ++s)
+      if (s < S) m[s] = fmaf(xv, ws[s][t], m[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s)
+    if (s < S) m[s] /= v1s[s];
+  float v[POOL_MAXS];
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s) v[s] = 0.f;
+  for (int t = 0; t < Tp; ++t) {
+    const float xv = x[(long)t * Cc];
+#pragma unroll
+    for (int s = 0; s < POOL_MAXS; ++s)
+      if (s < S) {
+        const float d = xv - m[s];
+        v[s] = fmaf(d * d, ws[s][t], v[s]);
+      }
+  }
+  const int D = Cc * Fh;
+  const int d = c * Fh + f;
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s)
+    if (s < S) {
+      float* o = stats + ((long)b * S + s) * 2 * D;
+      o[d] = m[s];
+      o[D + d] = sqrtf(v[s] / dens[s]);
+    }
+}
+
+}  // namespace pa
+
+extern "C" {
+
+int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
+                  const int* nearest_idx, float* stats, void* stream) {
+  if (B <= 0) return 0;
+  PA_REQUIRE(S >= 1 && S <= pa::POOL_MAXS && Tp <= pa::POOL_MAXT,
+             "pa_stats_pool: S <= %d and T' <= %d required (got %d, %d)", pa::POOL_MAXS,
+             pa::POOL_MAXT, S, Tp);
+  hipLaunchKernelGGL(pa::k_stats_pool, dim3(pa::cdiv(C, 256), Fh, B), dim3(256), 0,
+                     (hipStream_t)stream, feat, Fh, Tp, C, masks, S, Fm, nearest_idx, stats);
+  PA_CHECK_LAUNCH("pa_stats_pool");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,284 @@
+// WeSpeaker ResNet34 backbone on gfx950 (reference: models/embedding/wespeaker/resnet.py:84-145,
+// 399-430).  ~97 % of the pipeline's FLOPs are the 3x3 convolutions below.
+//
+// Activations are NHWC fp32: X[b][h][w][c], h = mel axis (80/40/20/10), w = time axis, so that the
+// channel dimension -- the MFMA K/N dimension -- is contiguous.  BatchNorm (eval) is folded on the
+// host: weights carry gamma/sqrt(var+eps), the epilogue adds the shift, the residual and the ReLU.
+//
+//   k_stem         conv3x3(1 -> 32) + BN + ReLU straight from the (B,T,80) fbank   (HBM-write bound)
+//   k_conv3x3      implicit GEMM on v_mfma_f32_32x32x2_f32: a workgroup owns TH x (32*TWT) output
+//                  pixels x BN output channels; per 16-channel input block the (halo'd) input patch
+//                  and the 9 x BN x 16 weight slab are staged in LDS once and reused by all 9 taps.
+//   k_gather_s2    strided pixel gather feeding the 1x1/stride-2 shortcut GEMM (pa_gemm_tn).
+#include "common.h"
+
+namespace pa {
+
+// ---------------------------------------------------------------------------------------------
+// stem: out[b][f][t][c] = relu( sum_{df,dt} w[c][df][dt] * fb[b][t+dt-1][f+df-1] + shift[c] )
+// grid = (ceil(T/64), F, B), block = 256: thread = (pixel t, 8-channel group)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ fb, int T, int F,
+                                              const float* __restrict__ w9,   // [9][32] tap-major
+                                              const float* __restrict__ shift,  // [32]
+                                              float* __restrict__ out) {
+  __shared__ float xs[3][66];
+  __shared__ float ws[9 * 32 + 32];
+  const int b = blockIdx.z, f = blockIdx.y, t0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 9 * 32 + 32; i += 256) ws[i] = i < 288 ? w9[i] : shift[i - 288];
+  for (int i = tid; i < 3 * 66; i += 256) {
+    const int df = i / 66, tt = i % 66;
+    const int ff = f + df - 1, t = t0 + tt - 1;
+    xs[df][tt] = (ff >= 0 && ff < F && t >= 0 && t < T) ? fb[((long)b * T + t) * F + ff] : 0.f;
+  }
+  __syncthreads();
+  const int px = tid >> 2, cg = (tid & 3) * 8;
+  if (t0 + px >= T) return;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int df = 0; df < 3; ++df)
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      const float xv = xs[df][px + dt];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv, ws[(df * 3 + dt) * 32 + cg + c], acc[c]);
+    }
+  float* o = out + (((long)b * F + f) * T + t0 + px) * 32 + cg;
+  float4 o0, o1;
+  o0.x = fmaxf(acc[0] + ws[288 + cg + 0], 0.f);
+  o0.y = fmaxf(acc[1] + ws[288 + cg + 1], 0.f);
+  o0.z = fmaxf(acc[2] + ws[288 + cg + 2], 0.f);
+  o0.w = fmaxf(acc[3] + ws[288 + cg + 3], 0.f);
+  o1.x = fmaxf(acc[4] + ws[288 + cg + 4], 0.f);
+  o1.y = fmaxf(acc[5] + ws[288 + cg + 5], 0.f);
+  o1.z = fmaxf(acc[6] + ws[288 + cg + 6], 0.f);
+  o1.w = fmaxf(acc[7] + ws[288 + cg + 7], 0.f);
+  reinterpret_cast<float4*>(o)[0] = o0;
+  reinterpret_cast<float4*>(o)[1] = o1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 (pad 1, stride S) + shift (+ residual) (+ ReLU), f32 MFMA implicit GEMM.
+//   X  : [B][H][W][CIN]          Wg : [9][COUT][CIN]  (tap = 3*dy+dx, BN scale folded)
+//   Y  : [B][Ho][Wo][COUT]       R  : residual, same shape as Y, or nullptr
+//   grid = (ceil(Wo/TW) * ceil(Ho/TH), COUT/BN, B), block = 256.
+// LDS images (row stride CB+4 = 20 floats = 5 x 16-B slots, conflict-free ds_read_b128):
+//   patch: S=1: [PH][PW][20];  S=2: [PH][2 (column parity)][PWH][20]  (de-interleaved columns so that
+//          the 32 lanes of an M-tile read consecutive entries)
+//   wts  : [9][BN][20]
+// MFMA k-order inside a 16-channel block: step q uses channel (lane>>5)*8 + q  (A and B alike).
+// ---------------------------------------------------------------------------------------------
+constexpr int CB = 16;
+constexpr int CLD = CB + 4;
+
+template <int S, int TH, int TWT>
+struct ConvGeom {
+  static constexpr int TW = 32 * TWT;
+  static constexpr int PH = (TH - 1) * S + 3;
+  static constexpr int PW = (TW - 1) * S + 3;
+  static constexpr int PWH = TW + 1;  // entries per column parity (S == 2)
+  static constexpr int PATCH = S == 1 ? PH * PW * CLD : PH * 2 * PWH * CLD;
+};
+
+template <int S, int TH, int TWT, int BN>
+__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ X, int H, int W, int CIN,
+                                                 const float* __restrict__ Wg,
+                                                 const float* __restrict__ shift,
+                                                 const float* __restrict__ R, float* __restrict__ Y,
+                                                 int Ho, int Wo, int COUT, int relu, int tiles_w) {
+  using G = ConvGeom<S, TH, TWT>;
+  constexpr int MT = TH * TWT;   // 32-pixel M-tiles per workgroup
+  constexpr int MPW = MT / 4;    // M-tiles per wave
+  constexpr int NT = BN / 32;    // N-tiles (every wave covers all of them)
+  static_assert(MT % 4 == 0, "M-tiles must split over 4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;
+  float* wts = smem + G::PATCH;
+
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * BN;
+  const int ty = blockIdx.x / tiles_w, tx = blockIdx.x % tiles_w;
+  const int y0 = ty * TH, x0 = tx * G::TW;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[MPW][NT];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const long xb = (long)b * H * W * CIN;
+  for (int c0 = 0; c0 < CIN; c0 += CB) {
+    __syncthreads();
+    // ---- stage input patch (4 threads x float4 per pixel)
+    for (int i = tid; i < G::PH * G::PW * (CB / 4); i += 256) {
+      const int c4 = i & 3, p = i >> 2;
+      const int py = p / G::PW, px = p % G::PW;
+      const int iy = y0 * S - 1 + py, ix = x0 * S - 1 + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = *reinterpret_cast<const float4*>(X + xb + ((long)iy * W + ix) * CIN + c0 + 4 * c4);
+      int off;
+      if (S == 1) off = (py * G::PW + px) * CLD + 4 * c4;
+      else off = ((py * 2 + (px & 1)) * G::PWH + (px >> 1)) * CLD + 4 * c4;
+      *reinterpret_cast<float4*>(patch + off) = v;
+    }
+    // ---- stage weights [9][BN][CB]
+    for (int i = tid; i < 9 * BN * (CB / 4); i += 256) {
+      const int c4 = i & 3, rn = i >> 2;  // rn = tap*BN + n
+      const int tap = rn / BN, n = rn % BN;
+      const float4 v =
+          *reinterpret_cast<const float4*>(Wg + ((long)tap * COUT + n0 + n) * CIN + c0 + 4 * c4);
+      *reinterpret_cast<float4*>(wts + rn * CLD + 4 * c4) = v;
+    }
+    __syncthreads();
+    // ---- 9 taps x 8 k-steps
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        float4 af[MPW][2], bf[NT][2];
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+          const int mt = wv * MPW + i;
+          const int yy = mt / TWT, xt = mt % TWT;
+          int off;
+          if (S == 1) off = ((yy + dy) * G::PW + 32 * xt + li + dx) * CLD;
+          else off = (((yy * 2 + dy) * 2 + (dx & 1)) * G::PWH + 32 * xt + li + (dx >> 1)) * CLD;
+          af[i][0] = *reinterpret_cast<const float4*>(patch + off + kh * 8);
+          af[i][1] = *reinterpret_cast<const float4*>(patch + off + kh * 8 + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int off = ((dy * 3 + dx) * BN + 32 * j + li) * CLD + kh * 8;
+          bf[j][0] = *reinterpret_cast<const float4*>(wts + off);
+          bf[j][1] = *reinterpret_cast<const float4*>(wts + off + 4);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < MPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              acc[i][j] = MFMA32(af[i][h].x, bf[j][h].x, acc[i][j]);
+              acc[i][j] = MFMA32(af[i][h].y, bf[j][h].y, acc[i][j]);
+              acc[i][j] = MFMA32(af[i][h].z, bf[j][h].z, acc[i][j]);
+              acc[i][j] = MFMA32(af[i][h].w, bf[j][h].w, acc[i][j]);
+            }
+      }
+  }
+  // ---- epilogue: lane holds channel n0 + 32j + li, pixels x = x0 + 32xt + (r&3) + 8(r>>2) + 4kh
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    const int mt = wv * MPW + i;
+    const int y = y0 + mt / TWT, xbase = x0 + 32 * (mt % TWT) + 4 * kh;
+    if (y >= Ho) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + 32 * j + li;
+      const float sh = shift[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = xbase + (r & 3) + 8 * (r >> 2);
+        if (x < Wo) {
+          const long o = (((long)b * Ho + y) * Wo + x) * COUT + n;
+          float v = acc[i][j][r] + sh;
+          if (R != nullptr) v += R[o];
+          if (relu) v = fmaxf(v, 0.f);
+          Y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// dense rows for the 1x1 stride-2 shortcut: A[((b*Ho+y)*Wo+x)][c] = X[b][2y][2x][c]
+__global__ __launch_bounds__(256) void k_gather_s2(const float* __restrict__ X, int H, int W, int C4,
+                                                   int Ho, int Wo, long total4,
+                                                   float* __restrict__ A) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = (int)(i % C4);
+  long p = i / C4;
+  const int x = (int)(p % Wo);
+  p /= Wo;
+  const int y = (int)(p % Ho);
+  const long b = p / Ho;
+  reinterpret_cast<float4*>(A)[i] =
+      reinterpret_cast<const float4*>(X)[(((b * H + 2 * y) * W) + 2 * x) * C4 + c4];
+}
+
+template <int S, int TH, int TWT, int BN>
+static int launch_conv(const float* X, int B, int H, int W, int CIN, const float* Wg,
+                       const float* shift, const float* R, float* Y, int COUT, int relu,
+                       hipStream_t st) {
+  using G = ConvGeom<S, TH, TWT>;
+  const int Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
+  const int tiles_w = cdiv(Wo, G::TW), tiles_h = cdiv(Ho, TH);
+  const size_t lds = (size_t)(G::PATCH + 9 * BN * CLD) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_conv3x3<S, TH, TWT, BN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_conv3x3<S, TH, TWT, BN>), dim3(tiles_w * tiles_h, COUT / BN, B), dim3(256),
+                     lds, st, X, H, W, CIN, Wg, shift, R, Y, Ho, Wo, COUT, relu, tiles_w);
+  return 0;
+}
+
+}  // namespace pa
+
+extern "C" {
+
+// conv1 + bn1 + relu of ResNet.forward (resnet.py:413-415), reading the (B,T,F) fbank directly
+int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, const float* shift,
+                   float* out, void* stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(pa::k_stem, dim3(pa::cdiv(T, 64), F, B), dim3(256), 0, (hipStream_t)stream, fbank,
+                     T, F, w9, shift, out);
+  PA_CHECK_LAUNCH("pa_resnet_stem");
+  return 0;
+}
+
+// BasicBlock convolutions (resnet.py:84-145): Y = [relu]( conv3x3_s(X) + shift [+ R] )
+int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, const float* shift,
+               const float* R, float* Y, int cout, int stride, int relu, void* stream) {
+  if (B <= 0) return 0;
+  PA_REQUIRE(cin % pa::CB == 0 && cout % 32 == 0, "pa_conv3x3: cin %% 16 and cout %% 32 required");
+  hipStream_t st = (hipStream_t)stream;
+  const int Ho = (H - 1) / stride + 1;
+  if (stride == 1) {
+    if (cout == 32) pa::launch_conv<1, 8, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else if (Ho >= 32) pa::launch_conv<1, 8, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else if (Ho >= 16) pa::launch_conv<1, 4, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else pa::launch_conv<1, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+  } else if (stride == 2) {
+    PA_REQUIRE(cout % 64 == 0, "pa_conv3x3: stride 2 needs cout %% 64 == 0");
+    if (Ho >= 16) pa::launch_conv<2, 4, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else pa::launch_conv<2, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+  } else {
+    PA_REQUIRE(false, "pa_conv3x3: stride %d not supported", stride);
+  }
+  PA_CHECK_LAUNCH("pa_conv3x3");
+  return 0;
+}
+
+int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream) {
+  PA_REQUIRE(C % 4 == 0, "pa_gather_s2: C %% 4 required");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total4 = (long)B * Ho * Wo * (C / 4);
+  if (total4 <= 0) return 0;
+  hipLaunchKernelGGL(pa::k_gather_s2, dim3(pa::cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, X,
+                     H, W, C / 4, Ho, Wo, total4, A);
+  PA_CHECK_LAUNCH("pa_gather_s2");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+"""Device-side WeSpeaker ResNet34 embedding extractor over `pa_emb_forward`
+(mirrors models/embedding/wespeaker/__init__.py:324-343 and the b3 interface of SURVEY.md 8b)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import ffi
+from .weights import EmbeddingPack
+
+
+class EmbeddingEngine:
+    """fbank -> ResNet34 -> weighted statistics pooling -> Linear over strided chunks of a
+    device-resident waveform.  The backbone runs once per chunk; all S masks are pooled from it."""
+
+    def __init__(self, pack: EmbeddingPack, max_chunks: int = 64):
+        self.pack = pack
+        self.max_chunks = max_chunks   # ~31 MB of activations per 10 s chunk
+        self._ws = None
+        self._idx_cache: dict = {}
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.pack.device)
+        return self._ws
+
+    def release_workspace(self):
+        self._ws = None
+
+    def num_pool_frames(self, num_samples: int) -> int:
+        return ffi.load().pa_emb_num_pool_frames(self.pack.struct, num_samples)
+
+    def nearest_index(self, mask_frames: int, pool_frames: int) -> torch.Tensor:
+        """source index of F.interpolate(mode="nearest") (blocks/pooling.py:113-117): obtained by
+        running torch's own op on an index ramp, so it is exactly what the reference does."""
+        key = (mask_frames, pool_frames)
+        if key not in self._idx_cache:
+            ramp = torch.arange(mask_frames, dtype=torch.float32).view(1, 1, -1)
+            idx = F.interpolate(ramp, size=pool_frames, mode="nearest").view(-1).to(torch.int32)
+            self._idx_cache[key] = idx.to(self.pack.device)
+        return self._idx_cache[key]
+
+    def forward_strided(self, wav: torch.Tensor, chunk_stride: int, num_chunks: int, num_samples: int,
+                        masks: torch.Tensor | None = None) -> torch.Tensor:
+        """wav: 1-D fp32 device tensor; masks: (C, S, Fm) fp32 device or None -> (C, S, D) fp32."""
+        lib = ffi.load()
+        w = self.pack.struct
+        dev = self.pack.device
+        if num_samples < 400:
+            raise ValueError("chunk shorter than one fbank frame (400 samples)")
+        S = 1 if masks is None else masks.shape[1]
+        Fm = 0 if masks is None else masks.shape[2]
+        Tp = self.num_pool_frames(num_samples)
+        idx = self.nearest_index(Fm, Tp) if masks is not None else None
+        if masks is not None:
+            masks = masks.to(dev, torch.float32).contiguous()
+        emb = torch.empty((num_chunks, S, w.embed_dim), dtype=torch.float32, device=dev)
+        c0 = 0
+        while c0 < num_chunks:
+            nb = min(self.max_chunks, num_chunks - c0)
+            ws = self._workspace(lib.pa_emb_workspace_bytes(w, nb, num_samples, S))
+            off = c0 * chunk_stride
+            sub = wav[off:]
+            rc = lib.pa_emb_forward(
+                w, ffi.c_fp(sub.data_ptr()), sub.numel(), chunk_stride, nb, num_samples,
+                ffi.ptr(masks[c0:c0 + nb]) if masks is not None else None, S, Fm,
+                ffi.ptr(idx) if idx is not None else None, ffi.ptr(emb[c0:c0 + nb]),
+                ffi.ptr(ws), ws.numel(), ffi.stream())
+            ffi.check(rc, "pa_emb_forward")
+            c0 += nb
+        return emb
+
+    def forward(self, waveforms: torch.Tensor, weights: torch.Tensor | None = None) -> torch.Tensor:
+        """(B,1,N) [, (B,Fm) or (B,S,Fm)] -> (B,D) or (B,S,D): the reference forward contract."""
+        B, ch, N = waveforms.shape
+        assert ch == 1
+        x = waveforms.to(self.pack.device, torch.float32).contiguous().view(-1)
+        squeeze = weights is None or weights.dim() == 2
+        m = None
+        if weights is not None:
+            m = weights.unsqueeze(1) if weights.dim() == 2 else weights
+        emb = self.forward_strided(x, N, B, N, m)
+        return emb[:, 0] if squeeze else emb

@@ -33,6 +33,23 @@ class SegWeights(C.Structure):
     ]
 
 
+PA_MAX_RES_BLOCKS = 64
+
+
+class EmbWeights(C.Structure):
+    _fields_ = [
+        ("num_mel", C.c_int32), ("embed_dim", C.c_int32), ("num_layers", C.c_int32),
+        ("num_blocks", C.c_int32 * 4), ("planes", C.c_int32 * 4),
+        ("fb_window", c_fp), ("fb_tw256", c_fp), ("fb_tw512", c_fp), ("fb_mel_w", c_fp),
+        ("fb_mel_lo", c_fp), ("fb_mel_hi", c_fp),
+        ("stem_w", c_fp), ("stem_shift", c_fp),
+        ("blk_w1", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift1", c_fp * PA_MAX_RES_BLOCKS),
+        ("blk_w2", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift2", c_fp * PA_MAX_RES_BLOCKS),
+        ("blk_wsc", c_fp * PA_MAX_RES_BLOCKS), ("blk_shiftsc", c_fp * PA_MAX_RES_BLOCKS),
+        ("seg1_w", c_fp), ("seg1_b", c_fp),
+    ]
+
+
 class LibraryNotBuilt(RuntimeError):
     pass
 
@@ -78,7 +95,21 @@ def load():
 
 # (name, argtypes, restype) of entry points added by later kernel files; declared when present so
 # that a partially built library fails at call time with a clear message rather than at import.
-_OPTIONAL: list[tuple] = []
+_OPTIONAL: list[tuple] = [
+    ("pa_emb_num_fbank_frames", [C.c_int], C.c_int),
+    ("pa_emb_num_pool_frames", [C.POINTER(EmbWeights), C.c_int], C.c_int),
+    ("pa_emb_workspace_bytes", [C.POINTER(EmbWeights), C.c_int, C.c_int, C.c_int], C.c_size_t),
+    ("pa_emb_forward", [C.POINTER(EmbWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int, c_fp,
+                        C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_size_t, c_fp], C.c_int),
+    ("pa_fbank", [c_fp, C.c_long, C.c_long, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                  C.c_int, c_fp, C.c_int, c_fp], C.c_int),
+    ("pa_resnet_stem", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_conv3x3", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
+                    C.c_int, c_fp], C.c_int),
+    ("pa_gather_s2", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
+    ("pa_stats_pool", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp,
+                       c_fp], C.c_int),
+]
 
 
 def _declare_optional(lib):

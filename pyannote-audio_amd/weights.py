@@ -163,3 +163,99 @@ class SegmentationPack:
         d = t.contiguous().to(self.device)
         self._keep.append(d)
         return C.c_void_p(d.data_ptr())
+
+
+# ---------------------------------------------------------------------------------------------
+# WeSpeaker ResNet34 (models/embedding/wespeaker/)
+# ---------------------------------------------------------------------------------------------
+def kaldi_mel_banks(num_bins: int = 80, padded: int = 512, sample_freq: float = 16000.0,
+                    low_freq: float = 20.0, high_freq: float = 0.0) -> torch.Tensor:
+    """torchaudio.compliance.kaldi.get_mel_banks (vtln_warp = 1), third party: restated from the
+    published algorithm -> (num_bins, padded // 2 + 1) fp32 with the right-most column zero
+    (call site: wespeaker/__init__.py:88-99)."""
+    import math
+    num_fft_bins = padded / 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    fft_bin_width = sample_freq / padded
+    mel_low = 1127.0 * math.log(1.0 + low_freq / 700.0)
+    mel_high = 1127.0 * math.log(1.0 + high_freq / 700.0)
+    delta = (mel_high - mel_low) / (num_bins + 1)
+    b = torch.arange(num_bins).unsqueeze(1)
+    left, center, right = mel_low + b * delta, mel_low + (b + 1.0) * delta, mel_low + (b + 2.0) * delta
+    mel = (1127.0 * (1.0 + (fft_bin_width * torch.arange(num_fft_bins)) / 700.0).log()).unsqueeze(0)
+    up = (mel - left) / (center - left)
+    down = (right - mel) / (right - center)
+    bins = torch.max(torch.zeros(1), torch.min(up, down))
+    return torch.nn.functional.pad(bins, (0, 1)).contiguous()
+
+
+def _fold_bn(sd: dict, prefix: str, eps: float = 1e-5):
+    scale = sd[prefix + ".weight"] / torch.sqrt(sd[prefix + ".running_var"] + eps)
+    shift = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale
+    return scale, shift
+
+
+class EmbeddingPack:
+    """Device-resident, kernel-ready WeSpeaker ResNet weights + the `pa_emb_weights` struct.
+    State-dict layout: resnet.conv1/bn1, resnet.layer{1..4}.{i}.{conv1,bn1,conv2,bn2,shortcut.0,
+    shortcut.1}, resnet.seg_1."""
+
+    def __init__(self, state_dict: dict, device: torch.device, num_blocks=(3, 4, 6, 3),
+                 num_mel: int = 80, sample_rate: int = 16000):
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
+        self.device = device
+        self._keep: list[torch.Tensor] = []
+        w = ffi.EmbWeights()
+        w.num_mel, w.num_layers = num_mel, 4
+        planes = [sd[f"resnet.layer{l + 1}.0.conv1.weight"].shape[0] for l in range(4)]
+        if planes[0] != 32:
+            raise NotImplementedError("stem kernel is built for m_channels = 32")
+        for l in range(4):
+            w.num_blocks[l] = int(num_blocks[l])
+            w.planes[l] = int(planes[l])
+        w.embed_dim = int(sd["resnet.seg_1.weight"].shape[0])
+        # fbank tables (fp64 -> fp32)
+        w.fb_window = self._up(torch.hamming_window(400, periodic=False, alpha=0.54, beta=0.46))
+        m = np.arange(256, dtype=np.float64)
+        tw256 = np.stack([np.cos(2 * np.pi * m / 256), -np.sin(2 * np.pi * m / 256)], -1)
+        k = np.arange(257, dtype=np.float64)
+        tw512 = np.stack([np.cos(2 * np.pi * k / 512), -np.sin(2 * np.pi * k / 512)], -1)
+        w.fb_tw256 = self._up(torch.from_numpy(tw256.astype(np.float32)))
+        w.fb_tw512 = self._up(torch.from_numpy(tw512.astype(np.float32)))
+        mel = kaldi_mel_banks(num_mel, 512, float(sample_rate))
+        self.mel = mel
+        nz = mel > 0
+        lo = torch.tensor([int(torch.nonzero(r)[0]) if r.any() else 0 for r in nz], dtype=torch.int32)
+        hi = torch.tensor([int(torch.nonzero(r)[-1]) if r.any() else -1 for r in nz], dtype=torch.int32)
+        w.fb_mel_w, w.fb_mel_lo, w.fb_mel_hi = self._up(mel), self._up(lo), self._up(hi)
+        # stem
+        sc, sh = _fold_bn(sd, "resnet.bn1")
+        cw = sd["resnet.conv1.weight"] * sc.view(-1, 1, 1, 1)  # (32,1,3,3)
+        w.stem_w = self._up(cw[:, 0].permute(1, 2, 0).reshape(9, 32))
+        w.stem_shift = self._up(sh)
+        blk = 0
+        for l in range(4):
+            for i in range(num_blocks[l]):
+                pre = f"resnet.layer{l + 1}.{i}"
+                for j, (cn, bn) in enumerate((("conv1", "bn1"), ("conv2", "bn2")), 1):
+                    sc, sh = _fold_bn(sd, f"{pre}.{bn}")
+                    cw = sd[f"{pre}.{cn}.weight"] * sc.view(-1, 1, 1, 1)  # (cout,cin,3,3)
+                    img = cw.permute(2, 3, 0, 1).reshape(9, cw.shape[0], cw.shape[1])
+                    getattr(w, f"blk_w{j}")[blk] = self._up(img).value
+                    getattr(w, f"blk_shift{j}")[blk] = self._up(sh).value
+                if f"{pre}.shortcut.0.weight" in sd:
+                    sc, sh = _fold_bn(sd, f"{pre}.shortcut.1")
+                    cw = sd[f"{pre}.shortcut.0.weight"][:, :, 0, 0] * sc.view(-1, 1)
+                    w.blk_wsc[blk] = self._up(cw).value
+                    w.blk_shiftsc[blk] = self._up(sh).value
+                blk += 1
+        w.seg1_w = self._up(sd["resnet.seg_1.weight"])
+        w.seg1_b = self._up(sd["resnet.seg_1.bias"])
+        self.struct = w
+
+    def _up(self, t: torch.Tensor):
+        d = t.contiguous().to(self.device)
+        self._keep.append(d)
+        return C.c_void_p(d.data_ptr())

@@ -1,0 +1,143 @@
+"""GPU parity: HIP embedding kernels (through the C ABI) vs the torch-CPU oracle.
+Tolerances: embeddings rtol 1e-4 / atol 1e-5 class; fbank compared on the linear power
+scale relative to the frame's peak (fp32 FFT round-off differs between pocketfft and our radix-4)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def emb(gpu_device):
+    from oracle import seeded_wespeaker
+    from pyannote_audio_amd.weights import EmbeddingPack
+    from pyannote_audio_amd.embedding import EmbeddingEngine
+    model = seeded_wespeaker(seed=4321)
+    pack = EmbeddingPack(model.state_dict(), gpu_device)
+    return model, pack, EmbeddingEngine(pack, max_chunks=3)
+
+
+def _wave(B, N, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = 0.1 * torch.randn(B, 1, N, generator=g)
+    x += 0.05 * torch.sin(torch.arange(N) * 0.05)[None, None] + 0.01
+    return x.clamp(-1, 1)
+
+
+def test_mel_tables_match_oracle(emb):
+    from oracle.models import kaldi_mel_banks
+    _, pack, _ = emb
+    assert torch.equal(pack.mel[:, :256], kaldi_mel_banks(80, 512, 16000.0))
+
+
+def test_fbank(emb, gpu_device):
+    import pyannote_audio_amd.ffi as ffi
+    lib = ffi.load()
+    model, pack, _ = emb
+    w = pack.struct
+    B, N = 3, 48000
+    x = _wave(B, N)
+    with torch.inference_mode():
+        ref = model.compute_fbank(x)
+    xd = x.view(-1).to(gpu_device)
+    T = lib.pa_emb_num_fbank_frames(N)
+    out = torch.full((B, T, 80), float("nan"), device=gpu_device)
+    ffi.check(lib.pa_fbank(ffi.ptr(xd), xd.numel(), N, B, N, w.fb_window, w.fb_tw256, w.fb_tw512,
+                           w.fb_mel_w, w.fb_mel_lo, w.fb_mel_hi, 80, ffi.ptr(out), 1, ffi.stream()), "fbank")
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    e = report("fbank_centered", out, ref)
+    assert e < 2e-3  # log-domain; low-energy bins carry FFT round-off of the whole frame
+
+
+def test_conv3x3_configs(gpu_device):
+    import pyannote_audio_amd.ffi as ffi
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(11)
+    # (cin, cout, H, W, stride): one per kernel instantiation + ragged edges
+    cases = [(32, 32, 80, 70, 1), (64, 64, 40, 45, 1), (128, 128, 20, 37, 1), (256, 256, 10, 70, 1),
+             (32, 64, 80, 71, 2), (128, 256, 20, 67, 2), (64, 128, 40, 50, 2)]
+    for cin, cout, H, W, s in cases:
+        B = 2
+        x = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+        sh = torch.randn(cout, generator=g)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        res = torch.randn(B, cout, Ho, Wo, generator=g)
+        ref = F.relu(F.conv2d(x.double(), wt.double(), stride=s, padding=1) + sh.double().view(1, -1, 1, 1)
+                     + res.double()).float()
+        xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        wd = wt.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous().to(gpu_device)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        shd = sh.to(gpu_device)
+        y = torch.full((B, Ho, Wo, cout), float("nan"), device=gpu_device)
+        ffi.check(lib.pa_conv3x3(ffi.ptr(xd), B, H, W, cin, ffi.ptr(wd), ffi.ptr(shd), ffi.ptr(rd),
+                                 ffi.ptr(y), cout, s, 1, ffi.stream()), "conv3x3")
+        torch.cuda.synchronize()
+        e = report(f"conv3x3_{cin}_{cout}_{H}x{W}_s{s}", y.permute(0, 3, 1, 2), ref)
+        assert e < 1e-4 * ref.abs().max().item()
+
+
+def test_stats_pool_kats(gpu_device):
+    """the reference's own known-answer tests (tests/test_stats_pool.py:28-131) on the HIP kernel."""
+    import pyannote_audio_amd.ffi as ffi
+    lib = ffi.load()
+
+    def run(x, w):
+        # x: (B, D, T) -> feat[b][f=1][t][c=D]
+        B, D, T = x.shape
+        feat = x.permute(0, 2, 1).contiguous().view(B, 1, T, D).to(gpu_device)
+        if w is None:
+            S, Fm, md, idx = 1, 0, None, None
+        else:
+            w3 = w if w.dim() == 3 else w.unsqueeze(1)
+            S, Fm = w3.shape[1], w3.shape[2]
+            md = w3.contiguous().to(gpu_device)
+            ramp = torch.arange(Fm, dtype=torch.float32).view(1, 1, -1)
+            idx = F.interpolate(ramp, size=T, mode="nearest").view(-1).to(torch.int32).to(gpu_device)
+        out = torch.empty(B, S, 2 * D, device=gpu_device)
+        ffi.check(lib.pa_stats_pool(ffi.ptr(feat), B, 1, T, D, ffi.ptr(md), S, Fm, ffi.ptr(idx),
+                                    ffi.ptr(out), ffi.stream()), "pool")
+        torch.cuda.synchronize()
+        out = out.cpu()
+        return out[:, 0] if (w is None or w.dim() == 2) else out
+
+    x = torch.Tensor([[[2.0, 4.0], [2.0, 4.0]], [[1.0, 1.0], [1.0, 1.0]]])
+    r = lambda y: torch.round(y, decimals=4)
+    assert torch.equal(r(run(x, None)), torch.Tensor([[3.0, 3.0, 1.4142, 1.4142], [1.0, 1.0, 0.0, 0.0]]))
+    w = torch.Tensor([[0.5, 0.01], [0.2, 0.1]])
+    assert torch.equal(r(run(x, w)), torch.Tensor([[2.0392, 2.0392, 1.4142, 1.4142], [1.0, 1.0, 0.0, 0.0]]))
+    w = torch.Tensor([[[0.1, 0.2], [0.2, 0.3]], [[0.001, 0.001], [0.2, 0.3]]])
+    assert torch.equal(r(run(x, w)), torch.Tensor(
+        [[[3.3333, 3.3333, 1.4142, 1.4142], [3.2, 3.2, 1.4142, 1.4142]],
+         [[1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 0.0, 0.0]]]))
+    x2 = torch.Tensor([[[2.0, 2.0], [2.0, 2.0]], [[1.0, 1.0], [1.0, 1.0]]])
+    w = torch.Tensor([[0.5, 0.5, 0.0], [0.0, 0.5, 0.5]])
+    assert torch.equal(r(run(x2, w)), torch.Tensor([[2.0, 2.0, 0.0, 0.0], [1.0, 1.0, 0.0, 0.0]]))
+    w = torch.Tensor([[0.5, 0.01], [0.0, 0.0]])
+    assert torch.equal(r(run(x, w)), torch.Tensor([[2.0392, 2.0392, 1.4142, 1.4142], [0.0, 0.0, 0.0, 0.0]]))
+
+
+@pytest.mark.parametrize("B,N", [(4, 48000), (2, 160000)])
+def test_emb_forward_end_to_end(emb, gpu_device, B, N):
+    model, pack, eng = emb
+    x = _wave(B, N, seed=5)
+    g = torch.Generator().manual_seed(2)
+    Fm = 589 if N == 160000 else 173
+    masks = (torch.rand(B, 3, Fm, generator=g) < 0.7).float()
+    masks[0, 2] = 0.0  # all-zero mask -> embedding = seg_1 bias path (tests/test_stats_pool.py:111-131)
+    with torch.inference_mode():
+        ref = model(x, weights=masks)
+        ref1 = model(x[:2])
+    out = eng.forward(x.to(gpu_device), masks.to(gpu_device))
+    out1 = eng.forward(x[:2].to(gpu_device))
+    torch.cuda.synchronize()
+    e = report(f"emb_B{B}_N{N}", out, ref)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-3, atol=2e-4 * ref.abs().max().item())
+    report(f"emb_unweighted_N{N}", out1, ref1)
+    assert torch.allclose(out1.cpu(), ref1, rtol=1e-3, atol=2e-4 * ref1.abs().max().item())
