@@ -156,6 +156,17 @@ int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* str
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Clustering distances (fp64, bit-identical to SciPy): replace the pdist inside
+ * scipy.cluster.hierarchy.linkage(X, "centroid", "euclidean") (pipelines/clustering.py:374-382) and
+ * scipy.spatial.distance.cdist(E, centroids, "cosine") (pipelines/clustering.py:190-200).
+ * ---------------------------------------------------------------------------------------- */
+/* out: condensed (N*(N-1)/2) upper triangle, pair order (0,1),(0,2),...,(N-2,N-1) */
+int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream);
+/* out: (NA, NB); norms: scratch of NA + NB doubles */
+int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D, double* out,
+                        double* norms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

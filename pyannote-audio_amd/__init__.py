@@ -4,3 +4,12 @@ Host-side mirror of the reference's Python interfaces over a C-ABI library of ha
 gfx950 kernels (`libpyannote_amd.so`, declared in include/pyannote_amd.h)."""
 
 __version__ = "0.1.0"
+
+from .core import Annotation, Segment, SlidingWindow, SlidingWindowFeature  # noqa: E402,F401
+from .audio import Audio  # noqa: E402,F401
+from .model import Model, PyanNet, WeSpeakerResNet34, Specifications, Problem, Resolution  # noqa: E402,F401
+from .pipeline import Pipeline  # noqa: E402,F401
+from .inference import Inference  # noqa: E402,F401
+from .agglomerative import AgglomerativeClustering, Clustering  # noqa: E402,F401
+from .speaker_verification import PretrainedSpeakerEmbedding  # noqa: E402,F401
+from .speaker_diarization import SpeakerDiarization, DiarizeOutput  # noqa: E402,F401

@@ -1,0 +1,126 @@
+// float64 distance kernels of the clustering stage on gfx950
+// (reference: pipelines/clustering.py:374-382 -> scipy.cluster.hierarchy.linkage(X, "centroid",
+//  "euclidean") whose first step is pdist; :190-200 -> scipy.spatial.distance.cdist(., ., "cosine")).
+//
+// Bit-exactness contract: SciPy accumulates sum_k (u_k - v_k)^2 (resp. sum_k u_k v_k) sequentially in
+// k, in double, with separately rounded multiply and add (its x86-64 baseline build has no FMA).  The
+// kernels below keep one accumulator per output pair, walk k in ascending order and use
+// __dmul_rn/__dadd_rn so that the compiler cannot contract to FMA.  HBM-bound on the condensed
+// output for large N (8 B per pair); the arithmetic (3 flop per pair and k) is far from the fp64 peak.
+#include "common.h"
+
+namespace pa {
+
+constexpr int PD_T = 64;   // pairs tile edge
+constexpr int PD_K = 32;   // k chunk
+constexpr int PD_LD = PD_K + 1;
+
+// grid = (ceil(N/64), ceil(N/64)) with blockIdx.x >= blockIdx.y skipped lower triangle; block = 256
+__global__ __launch_bounds__(256) void k_pdist_f64(const double* __restrict__ X, int N, int D,
+                                                    double* __restrict__ out) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  __shared__ double As[PD_T * PD_LD];
+  __shared__ double Bs[PD_T * PD_LD];
+  const int tid = threadIdx.x;
+  const int ti = tid >> 4, tj = tid & 15;  // 16 x 16 threads, 4 x 4 pairs each (rows ti+16a, cols tj+16b)
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int k0 = 0; k0 < D; k0 += PD_K) {
+    __syncthreads();
+    for (int i = tid; i < PD_T * PD_K; i += 256) {
+      const int r = i / PD_K, c = i % PD_K;
+      const int gi = bi * PD_T + r, gj = bj * PD_T + r, k = k0 + c;
+      As[r * PD_LD + c] = (gi < N && k < D) ? X[(long)gi * D + k] : 0.0;
+      Bs[r * PD_LD + c] = (gj < N && k < D) ? X[(long)gj * D + k] : 0.0;
+    }
+    __syncthreads();
+    const int kmax = min(PD_K, D - k0);
+    for (int k = 0; k < kmax; ++k) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = As[(ti + 16 * a) * PD_LD + k];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = Bs[(tj + 16 * b) * PD_LD + k];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double d = __dsub_rn(av[a], bv[b]);
+          acc[a][b] = __dadd_rn(acc[a][b], __dmul_rn(d, d));
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const long i = bi * PD_T + ti + 16 * a, j = bj * PD_T + tj + 16 * b;
+      if (i < j && j < N)
+        out[(long)N * i - i * (i + 1) / 2 + (j - i - 1)] = __dsqrt_rn(acc[a][b]);
+    }
+}
+
+__global__ void k_row_norms_f64(const double* __restrict__ X, int N, int D, double* __restrict__ nrm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  for (int k = 0; k < D; ++k) {
+    const double v = X[(long)i * D + k];
+    s = __dadd_rn(s, __dmul_rn(v, v));
+  }
+  nrm[i] = __dsqrt_rn(s);
+}
+
+// out[i][j] = 1 - clip(<a_i, b_j> / (|a_i| |b_j|));  grid = NA, block = 128 (threads stride over j)
+__global__ __launch_bounds__(128) void k_cdist_cosine_f64(const double* __restrict__ A,
+                                                           const double* __restrict__ B, int NB, int D,
+                                                           const double* __restrict__ nA,
+                                                           const double* __restrict__ nB,
+                                                           double* __restrict__ out) {
+  extern __shared__ double us[];
+  const int i = blockIdx.x;
+  for (int k = threadIdx.x; k < D; k += 128) us[k] = A[(long)i * D + k];
+  __syncthreads();
+  const double na = nA[i];
+  for (int j = threadIdx.x; j < NB; j += 128) {
+    const double* v = B + (long)j * D;
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) s = __dadd_rn(s, __dmul_rn(us[k], v[k]));
+    double c = __ddiv_rn(s, __dmul_rn(na, nB[j]));
+    if (fabs(c) > 1.0) c = copysign(1.0, c);
+    out[(long)i * NB + j] = __dsub_rn(1.0, c);
+  }
+}
+
+}  // namespace pa
+
+extern "C" {
+
+// scipy.spatial.distance.pdist(X, "euclidean"): condensed upper triangle, row-major pair order
+int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream) {
+  if (N < 2) return 0;
+  const int nt = pa::cdiv(N, pa::PD_T);
+  hipLaunchKernelGGL(pa::k_pdist_f64, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, X, N, D, out);
+  PA_CHECK_LAUNCH("pa_pdist_f64");
+  return 0;
+}
+
+// scipy.spatial.distance.cdist(A, B, "cosine"); `norms` is scratch for NA + NB doubles
+int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D, double* out,
+                        double* norms, void* stream) {
+  if (NA <= 0 || NB <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pa::k_row_norms_f64, dim3(pa::cdiv(NA, 128)), dim3(128), 0, st, A, NA, D, norms);
+  hipLaunchKernelGGL(pa::k_row_norms_f64, dim3(pa::cdiv(NB, 128)), dim3(128), 0, st, B, NB, D,
+                     norms + NA);
+  hipLaunchKernelGGL(pa::k_cdist_cosine_f64, dim3(NA), dim3(128), (size_t)D * sizeof(double), st, A, B,
+                     NB, D, norms, norms + NA, out);
+  PA_CHECK_LAUNCH("pa_cdist_cosine_f64");
+  return 0;
+}
+
+}  // extern "C"

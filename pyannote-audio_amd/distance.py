@@ -1,0 +1,49 @@
+"""float64 distance kernels for clustering: GPU (`pa_pdist_f64`, `pa_cdist_cosine_f64`) with results
+bit-identical to SciPy's `pdist(X, "euclidean")` / `cdist(A, B, "cosine")`.
+
+SciPy computes Euclidean distances as a sequential-k sum of (u_k - v_k)^2 in double without FMA
+contraction, then sqrt; cosine as 1 - <u,v> / (|u| |v|) with sequential dot products.  The kernels
+reproduce that summation order with explicit `__dmul_rn/__dadd_rn` (see csrc/cluster.hip).  Small
+problems stay in SciPy: the launch + copy overhead exceeds the work."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy.spatial.distance import cdist as _scipy_cdist
+from scipy.spatial.distance import pdist as _scipy_pdist
+
+from . import ffi
+
+def _use_gpu(device, n: int) -> bool:
+    """GPU kernels whenever the clustering object lives on a GPU (pipeline.to(cuda)); a clustering
+    object used stand-alone on the host (device None / cpu) calls SciPy, i.e. the reference's own
+    implementation.  A missing kernel on a GPU device is an error, never a silent downgrade."""
+    if device is None or getattr(device, "type", None) != "cuda" or n < 2:
+        return False
+    ffi.require_gpu()
+    return True
+
+
+def pdist_euclidean(X: np.ndarray, device=None) -> np.ndarray:
+    """condensed float64 Euclidean distance matrix of the rows of X (any float dtype)."""
+    n = X.shape[0]
+    if not _use_gpu(device, n):
+        return _scipy_pdist(X, metric="euclidean")
+    lib = ffi.load()
+    Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device)
+    out = torch.empty(n * (n - 1) // 2, dtype=torch.float64, device=device)
+    ffi.check(lib.pa_pdist_f64(ffi.ptr(Xd), n, X.shape[1], ffi.ptr(out), ffi.stream()), "pa_pdist_f64")
+    return out.cpu().numpy()
+
+
+def cdist(A: np.ndarray, B: np.ndarray, metric: str = "cosine", device=None) -> np.ndarray:
+    if metric != "cosine" or not _use_gpu(device, A.shape[0]):
+        return _scipy_cdist(A, B, metric=metric)
+    lib = ffi.load()
+    Ad = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(device)
+    Bd = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float64)).to(device)
+    out = torch.empty((A.shape[0], B.shape[0]), dtype=torch.float64, device=device)
+    norms = torch.empty(A.shape[0] + B.shape[0], dtype=torch.float64, device=device)
+    ffi.check(lib.pa_cdist_cosine_f64(ffi.ptr(Ad), A.shape[0], ffi.ptr(Bd), B.shape[0], A.shape[1],
+                                      ffi.ptr(out), ffi.ptr(norms), ffi.stream()), "pa_cdist_cosine_f64")
+    return out.cpu().numpy()

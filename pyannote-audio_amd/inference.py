@@ -1,0 +1,201 @@
+"""Sliding-window inference engine, device resident (mirrors core/inference.py: __init__ :78-167,
+slide :217-373, aggregate :498-620, trim :622-667).
+
+Differences in mechanism, not in results: the waveform is uploaded to HBM once and chunks are
+gathered by the kernels through (offset, stride) arithmetic, instead of `unfold` + one H2D copy and
+one D2H copy per batch (the reference's hot loop #1, inference.py:295-305)."""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .audio import AudioFile, Audio
+from .core import Segment, SlidingWindow, SlidingWindowFeature
+from .model import Model, Resolution
+from .pipeline import BaseInference
+
+
+class Inference(BaseInference):
+    def __init__(self, model: Model, window: str = "sliding", duration: Optional[float] = None,
+                 step: Optional[float] = None, pre_aggregation_hook: Optional[Callable] = None,
+                 skip_aggregation: bool = False, skip_conversion: bool = False,
+                 device: Optional[torch.device] = None, batch_size: int = 32):
+        self.model = model
+        if device is None:
+            device = self.model.device
+        self.device = device
+        self.model.eval()
+        self.model.to(self.device)
+        specifications = self.model.specifications
+        if window not in ["sliding", "whole"]:
+            raise ValueError('`window` must be "sliding" or "whole".')
+        if window == "whole" and specifications.resolution == Resolution.FRAME:
+            warnings.warn('Using "whole" `window` inference with a frame-based model might lead to bad '
+                          'results and huge memory consumption: it is recommended to set `window` to '
+                          '"sliding".')
+        self.window = window
+        training_duration = specifications.duration
+        duration = duration or training_duration
+        if training_duration != duration:
+            warnings.warn(f"Model was trained with {training_duration:g}s chunks, and you requested "
+                          f"{duration:g}s chunks for inference: this might lead to suboptimal results.")
+        self.duration = duration
+        self.skip_conversion = skip_conversion
+        self.skip_aggregation = skip_aggregation
+        self.pre_aggregation_hook = pre_aggregation_hook
+        self.warm_up = specifications.warm_up
+        step = step or (0.1 * self.duration if self.warm_up[0] == 0.0 else self.warm_up[0])
+        if step > self.duration:
+            raise ValueError(
+                f"Step between consecutive chunks is set to {step:g}s, while chunks are only "
+                f"{self.duration:g}s long, leading to gaps between consecutive chunks. Either decrease "
+                f"step or increase duration.")
+        self.step = step
+        # kept for API compatibility: the engine sizes its own launch groups; the
+        # value only sets the granularity at which `hook` is called.
+        self.batch_size = batch_size
+        # device-side copy of the last hard segmentation, for the embedding stage
+        self.last_device_output: Optional[torch.Tensor] = None
+
+    def to(self, device: torch.device) -> "Inference":
+        if not isinstance(device, torch.device):
+            raise TypeError(
+                f"`device` must be an instance of `torch.device`, got `{type(device).__name__}`")
+        self.model.to(device)
+        self.device = device
+        return self
+
+    # ---------------------------------------------------------------------------------------
+    def slide(self, waveform: torch.Tensor, sample_rate: int, hook: Optional[Callable] = None,
+              chunk_range: Optional[Tuple[int, int]] = None) -> SlidingWindowFeature:
+        """waveform: (1, num_samples), host or device.  `chunk_range` restricts processing to chunks
+        [begin, end) (multi-GPU sharding); geometry is always that of the whole file."""
+        specifications = self.model.specifications
+        if specifications.resolution != Resolution.FRAME or not specifications.powerset:
+            raise NotImplementedError("the accelerated sliding window covers frame-level powerset "
+                                      "segmentation models (the 3.1 hot path)")
+        window_size: int = self.model.audio.get_num_samples(self.duration)
+        step_size: int = round(self.step * sample_rate)
+        _, num_samples = waveform.shape
+        num_chunks, has_last_chunk = self.num_chunks(num_samples, window_size, step_size)
+        total = num_chunks + has_last_chunk
+        begin, end = (0, total) if chunk_range is None else chunk_range
+
+        wav = waveform.to(self.model.device, torch.float32).contiguous().view(-1)
+        if hook is not None:
+            hook(completed=0, total=total)
+        engine = self.model.engine
+        want_logp = self.skip_conversion
+        sub = wav[begin * step_size:]
+        logp, ml = engine.forward_strided(sub, step_size, end - begin, window_size,
+                                          want_logp=want_logp, want_multilabel=not want_logp)
+        self.last_device_output = ml
+        outputs = (logp if want_logp else ml.to(torch.float32)).cpu().numpy()
+        if hook is not None:
+            hook(completed=total, total=total)
+
+        frames = self.model.receptive_field
+        if (self.skip_aggregation or (specifications.permutation_invariant
+                                      and self.pre_aggregation_hook is None)):
+            chunks = SlidingWindow(start=begin * self.step, duration=self.duration, step=self.step) \
+                if begin else SlidingWindow(start=0.0, duration=self.duration, step=self.step)
+            return SlidingWindowFeature(outputs, chunks)
+
+        if self.pre_aggregation_hook is not None:
+            outputs = self.pre_aggregation_hook(outputs)
+        aggregated = self.aggregate(
+            SlidingWindowFeature(outputs, SlidingWindow(start=0.0, duration=self.duration,
+                                                        step=self.step)),
+            frames, warm_up=self.warm_up, hamming=True, missing=0.0)
+        if has_last_chunk:
+            aggregated.data = aggregated.crop(Segment(0.0, num_samples / sample_rate), mode="loose")
+        return aggregated
+
+    @staticmethod
+    def num_chunks(num_samples: int, window_size: int, step_size: int) -> Tuple[int, bool]:
+        """inference.py:258-278: complete chunks from `unfold` + one zero-padded orphan chunk."""
+        n = (num_samples - window_size) // step_size + 1 if num_samples >= window_size else 0
+        has_last = (num_samples < window_size) or (num_samples - window_size) % step_size > 0
+        return n, bool(has_last)
+
+    def __call__(self, file: AudioFile, hook: Optional[Callable] = None):
+        waveform, sample_rate = Audio(self.model.audio.sample_rate, mono="downmix")(file)
+        if self.window == "sliding":
+            return self.slide(waveform, sample_rate, hook=hook)
+        out = self.model(waveform[None].to(self.model.device))
+        return out[0].cpu().numpy()
+
+    # ---------------------------------------------------------------------------------------
+    @staticmethod
+    def aggregate(scores: SlidingWindowFeature, frames: SlidingWindow,
+                  warm_up: Tuple[float, float] = (0.0, 0.0), epsilon: float = 1e-12,
+                  hamming: bool = False, missing: float = np.nan,
+                  skip_average: bool = False) -> SlidingWindowFeature:
+        """Overlap-add aggregation (inference.py:498-620).  Same arithmetic, in the same order
+        (contributions are added chunk by chunk, in float64, into float32 accumulators)."""
+        data = scores.data if isinstance(scores, SlidingWindowFeature) else np.asarray(scores)
+        num_chunks, F, K = data.shape
+        chunks = scores.sliding_window
+        frames = SlidingWindow(start=chunks.start, duration=frames.duration, step=frames.step)
+        w = np.hamming(F).reshape(-1, 1) if hamming else np.ones((F, 1))
+        warm = np.ones((F, 1))
+        left = round(warm_up[0] / chunks.duration * F)
+        warm[:left] = epsilon
+        right = round(warm_up[1] / chunks.duration * F)
+        warm[F - right:] = epsilon
+        num_frames = frames.closest_frame(
+            chunks.start + chunks.duration + (num_chunks - 1) * chunks.step + 0.5 * frames.duration) + 1
+        agg = np.zeros((num_frames, K), dtype=np.float32)
+        cnt = np.zeros((num_frames, K), dtype=np.float32)
+        msk = np.zeros((num_frames, K), dtype=np.float32)
+        starts = aggregate_start_frames(chunks, frames, num_chunks)
+        nan = np.isnan(data)
+        has_nan = bool(nan.any())
+        ww = w * warm
+        for c in range(num_chunks):
+            s = starts[c]
+            if has_nan:
+                m = 1 - nan[c]
+                sc = np.where(nan[c], 0.0, data[c])
+                agg[s:s + F] += sc * m * w * warm
+                cnt[s:s + F] += m * w * warm
+                np.maximum(msk[s:s + F], m, out=msk[s:s + F])
+            else:
+                agg[s:s + F] += data[c] * w * warm
+                cnt[s:s + F] += ww
+        if not has_nan:
+            if num_chunks:
+                msk[starts[0]:starts[-1] + F] = 1.0
+                # frames between two non-adjacent chunks (step > duration never happens) stay 0
+        average = agg if skip_average else agg / np.maximum(cnt, epsilon)
+        average[msk == 0.0] = missing
+        return SlidingWindowFeature(average, frames)
+
+    @staticmethod
+    def trim(scores: SlidingWindowFeature, warm_up: Tuple[float, float] = (0.1, 0.1)
+             ) -> SlidingWindowFeature:
+        """inference.py:622-667"""
+        assert scores.data.ndim == 3
+        _, num_frames, _ = scores.data.shape
+        chunks = scores.sliding_window
+        left = round(num_frames * warm_up[0])
+        right = round(num_frames * warm_up[1])
+        step_frames = round(num_frames * chunks.step / chunks.duration)
+        if num_frames - left - right < step_frames:
+            warnings.warn(f"Total `warm_up` is so large ({sum(warm_up) * 100:g}% of each chunk) that "
+                          f"resulting trimmed scores does not cover a whole step ({chunks.step:g}s)")
+        new_chunks = SlidingWindow(start=chunks.start + warm_up[0] * chunks.duration, step=chunks.step,
+                                   duration=(1 - warm_up[0] - warm_up[1]) * chunks.duration)
+        return SlidingWindowFeature(scores.data[:, left:num_frames - right], new_chunks)
+
+
+def aggregate_start_frames(chunks: SlidingWindow, frames: SlidingWindow, num_chunks: int) -> np.ndarray:
+    """start frame of every chunk: frames.closest_frame(chunk.start + 0.5 * frames.duration)
+    (inference.py:596), evaluated for all chunks at once with identical float64 operations."""
+    c = np.arange(num_chunks, dtype=np.float64)
+    chunk_start = chunks.start + c * chunks.step
+    t = chunk_start + 0.5 * frames.duration
+    return np.rint((t - frames.start - 0.5 * frames.duration) / frames.step).astype(np.int64)

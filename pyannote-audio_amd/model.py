@@ -1,0 +1,402 @@
+"""Model objects of the hot path: specifications, checkpoint reader/writer, and the two models the
+3.1 pipeline uses (PyanNet segmentation, WeSpeaker ResNet34 embedding) as thin host objects over the
+HIP engines.  Mirrors core/model.py (specifications :114-153, receptive_field :168-184,
+on_save/load_checkpoint :244-262, from_pretrained :497-655) and core/task.py:59-137.
+
+Weights stay on the host (reference state-dict layout) until `.to(torch.device("cuda"))`, exactly like
+the reference keeps modules on CPU until `pipeline.to(device)` (core/pipeline.py:591-611).  Calling a
+model that has not been moved to a GPU raises: there is no CPU compute path in this package."""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import pickle
+import sys
+import types
+from dataclasses import dataclass
+from enum import Enum
+from functools import cached_property
+from pathlib import Path
+from typing import List, Optional, Text, Tuple
+
+import numpy as np
+import scipy.special
+import torch
+
+from . import ffi
+from .core import SlidingWindow
+
+
+# ---------------------------------------------------------------------------------------------
+# core/task.py:59-137
+# ---------------------------------------------------------------------------------------------
+class Problem(Enum):
+    BINARY_CLASSIFICATION = 0
+    MONO_LABEL_CLASSIFICATION = 1
+    MULTI_LABEL_CLASSIFICATION = 2
+    REPRESENTATION = 3
+    REGRESSION = 4
+
+
+class Resolution(Enum):
+    FRAME = 1
+    CHUNK = 2
+
+
+@dataclass
+class Specifications:
+    problem: Problem
+    resolution: Resolution
+    duration: float
+    min_duration: Optional[float] = None
+    warm_up: Optional[Tuple[float, float]] = (0.0, 0.0)
+    classes: Optional[List[Text]] = None
+    powerset_max_classes: Optional[int] = None
+    permutation_invariant: bool = False
+
+    @cached_property
+    def powerset(self) -> bool:
+        if self.powerset_max_classes is None:
+            return False
+        if self.problem != Problem.MONO_LABEL_CLASSIFICATION:
+            raise ValueError("`powerset_max_classes` only makes sense with multi-class "
+                             "classification problems.")
+        return True
+
+    @cached_property
+    def num_powerset_classes(self) -> int:
+        return int(sum(scipy.special.binom(len(self.classes), i)
+                       for i in range(0, self.powerset_max_classes + 1)))
+
+    def __len__(self):
+        return 1
+
+    def __iter__(self):
+        yield self
+
+
+# pickled checkpoints reference these classes by their reference module path
+_REF_TASK_MODULE = "pyannote.audio.core.task"
+for _k in (Problem, Resolution, Specifications):
+    _k.__module__ = _REF_TASK_MODULE
+
+
+class AttributeDict(dict):
+    """stand-in for lightning's AttributeDict (hyper_parameters container)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class _Opaque:
+    """placeholder for pickled objects we never need (legacy Introspection, loss functions, ...)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__["state"] = state
+
+
+class _ShimUnpickler(pickle.Unpickler):
+    """Restricted unpickler for Lightning / pyannote.audio checkpoints when neither package is
+    installed: maps the handful of foreign classes to local stand-ins."""
+
+    _LOCAL = {"Specifications": Specifications, "Problem": Problem, "Resolution": Resolution}
+
+    def find_class(self, module, name):
+        if module.startswith("pyannote.audio") and name in self._LOCAL:
+            return self._LOCAL[name]
+        if name == "AttributeDict":
+            return AttributeDict
+        if module.startswith(("pyannote.", "lightning", "pytorch_lightning", "torchmetrics",
+                              "pytorch_metric_learning", "asteroid")):
+            return _Opaque
+        return super().find_class(module, name)
+
+
+_shim_pickle = types.ModuleType("pyannote_audio_amd._shim_pickle")
+_shim_pickle.Unpickler = _ShimUnpickler
+_shim_pickle.load = lambda f, **kw: _ShimUnpickler(f, **kw).load()
+_shim_pickle.__name__ = "pickle"
+for _n in ("dumps", "dump", "loads", "Pickler", "PickleError", "UnpicklingError", "HIGHEST_PROTOCOL"):
+    setattr(_shim_pickle, _n, getattr(pickle, _n))
+
+
+@contextlib.contextmanager
+def _reference_task_module():
+    """Temporarily expose our Specifications/Problem/Resolution as `pyannote.audio.core.task` so that
+    pickling by reference produces checkpoints the reference can read (core/model.py:244-256)."""
+    created = []
+    parts = _REF_TASK_MODULE.split(".")
+    for i in range(1, len(parts) + 1):
+        name = ".".join(parts[:i])
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+            created.append(name)
+    mod = sys.modules[_REF_TASK_MODULE]
+    saved = {k: getattr(mod, k, None) for k in ("Specifications", "Problem", "Resolution")}
+    mod.Specifications, mod.Problem, mod.Resolution = Specifications, Problem, Resolution
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                delattr(mod, k)
+            else:
+                setattr(mod, k, v)
+        for name in reversed(created):
+            sys.modules.pop(name, None)
+
+
+def load_checkpoint(path) -> dict:
+    """torch.load of a Lightning checkpoint dict {state_dict, hyper_parameters, "pyannote.audio": ...}
+    (core/model.py:602-604 uses weights_only=False; so must we, through the restricted unpickler)."""
+    if isinstance(path, (str, Path)) and os.path.isdir(path):
+        path = Path(path) / "pytorch_model.bin"
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_shim_pickle)
+
+
+def save_checkpoint(path, state_dict: dict, hyper_parameters: dict, architecture: Tuple[str, str],
+                    specifications: Specifications, version: str = "3.1.0"):
+    """Write a checkpoint in the reference's on-disk format (core/model.py:244-256)."""
+    ckpt = {
+        "state_dict": {k: v.detach().cpu() for k, v in state_dict.items()},
+        "hyper_parameters": dict(hyper_parameters),
+        "pytorch-lightning_version": "2.6.1",
+        "pyannote.audio": {
+            "versions": {"pyannote.audio": version},
+            "architecture": {"module": architecture[0], "class": architecture[1]},
+            "specifications": specifications,
+        },
+    }
+    with _reference_task_module():
+        torch.save(ckpt, path)
+
+
+# ---------------------------------------------------------------------------------------------
+# receptive-field arithmetic (utils/receptive_field.py:26-165)
+# ---------------------------------------------------------------------------------------------
+def multi_conv_num_frames(n, kernel_size, stride, padding, dilation):
+    for k, s, p, d in zip(kernel_size, stride, padding, dilation):
+        n = 1 + (n + 2 * p - d * (k - 1) - 1) // s
+    return n
+
+
+def multi_conv_receptive_field_size(num_frames, kernel_size, stride, padding, dilation):
+    size = num_frames
+    for k, s, p, d in reversed(list(zip(kernel_size, stride, padding, dilation))):
+        size = 1 + (k - 1) * d + (size - 1) * s - 2 * p
+    return size
+
+
+def multi_conv_receptive_field_center(frame, kernel_size, stride, padding, dilation):
+    c = frame
+    for k, s, p, d in reversed(list(zip(kernel_size, stride, padding, dilation))):
+        c = c * s + ((1 + (k - 1) * d) - 1) // 2 - p
+    return c
+
+
+class _AudioSpec:
+    """what callers read from `model.audio` (core/io.py): sample rate, mono, get_num_samples."""
+
+    def __init__(self, sample_rate: int = 16000, mono: str = "downmix"):
+        self.sample_rate = sample_rate
+        self.mono = mono
+
+    def get_num_samples(self, duration: float, sample_rate: Optional[int] = None) -> int:
+        sample_rate = sample_rate or self.sample_rate
+        return round(duration * sample_rate)  # core/io.py:292-304
+
+
+class Model:
+    """Host-side model object (not an nn.Module: the weights are kernel-ready device images)."""
+
+    ARCHITECTURE = ("", "")
+
+    def __init__(self, state_dict: dict, hparams: dict, specifications: Specifications):
+        self._state_dict = {k: v.detach().cpu() for k, v in state_dict.items()}
+        self.hparams = AttributeDict(hparams)
+        self.specifications = specifications
+        self.device = torch.device("cpu")
+        self.audio = _AudioSpec(int(self.hparams.get("sample_rate", 16000)), "downmix")
+        self._engine = None
+
+    # -- reference API surface
+    def state_dict(self):
+        return self._state_dict
+
+    def eval(self):
+        return self
+
+    def to(self, device: torch.device):
+        if not isinstance(device, torch.device):
+            raise TypeError(
+                f"`device` must be an instance of `torch.device`, got `{type(device).__name__}`")
+        if device.type == "cuda":
+            ffi.require_gpu()
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            if self._engine is None or self.device != device:
+                self._engine = self._build_engine(device)
+        else:
+            self._engine = None
+        self.device = device
+        return self
+
+    def cuda(self, index: Optional[int] = None):
+        return self.to(torch.device("cuda") if index is None else torch.device("cuda", index))
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            raise RuntimeError(
+                f"{type(self).__name__} lives on {self.device}: this package has no CPU compute path. "
+                "Move it to an MI355X first: model.to(torch.device('cuda')).")
+        return self._engine
+
+    @cached_property
+    def receptive_field(self) -> SlidingWindow:
+        size = self.receptive_field_size(num_frames=1)
+        step = self.receptive_field_size(num_frames=2) - size
+        start = self.receptive_field_center(frame=0) - (size - 1) / 2
+        sr = self.audio.sample_rate
+        return SlidingWindow(start=start / sr, duration=size / sr, step=step / sr)
+
+    def save(self, path):
+        save_checkpoint(path, self._state_dict, dict(self.hparams), self.ARCHITECTURE,
+                        self.specifications)
+
+    @classmethod
+    def from_pretrained(cls, checkpoint, map_location=None, strict: bool = True,
+                        subfolder: Optional[str] = None, revision: Optional[str] = None,
+                        token=None, cache_dir=None, **kwargs) -> Optional["Model"]:
+        """core/model.py:497-655 restricted to local checkpoints (no network in scope): a path to
+        `pytorch_model.bin`, a directory containing it (optionally `subfolder`), or a byte buffer."""
+        if isinstance(checkpoint, (str, Path)):
+            p = Path(checkpoint)
+            if p.is_dir():
+                p = p / subfolder / "pytorch_model.bin" if subfolder else p / "pytorch_model.bin"
+            if not p.exists():
+                raise FileNotFoundError(
+                    f"{checkpoint!s}: only local checkpoints are supported (no Hugging Face download "
+                    "in this build: SURVEY.md section 2, row 14)")
+            checkpoint = p
+        ckpt = load_checkpoint(checkpoint)
+        arch = ckpt["pyannote.audio"]["architecture"]["class"]
+        klass = {"PyanNet": PyanNet, "WeSpeakerResNet34": WeSpeakerResNet34}.get(arch)
+        if klass is None:
+            raise NotImplementedError(
+                f"architecture {arch!r} is outside the accelerated hot path (PyanNet, WeSpeakerResNet34)")
+        return klass(ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {})),
+                     ckpt["pyannote.audio"]["specifications"])
+
+
+class PyanNet(Model):
+    """models/segmentation/PyanNet.py:38-240 over the HIP segmentation engine."""
+
+    ARCHITECTURE = ("pyannote.audio.models.segmentation.PyanNet", "PyanNet")
+    _K = [251, 3, 5, 3, 5, 3]
+
+    def _conv(self):
+        s = int((self.hparams.get("sincnet") or {}).get("stride", 10))
+        return self._K, [s, 3, 1, 3, 1, 3], [0] * 6, [1] * 6
+
+    def num_frames(self, num_samples: int) -> int:
+        return multi_conv_num_frames(num_samples, *self._conv())
+
+    def receptive_field_size(self, num_frames: int = 1) -> int:
+        return multi_conv_receptive_field_size(num_frames, *self._conv())
+
+    def receptive_field_center(self, frame: int = 0) -> int:
+        return multi_conv_receptive_field_center(frame, *self._conv())
+
+    @property
+    def dimension(self) -> int:
+        s = self.specifications
+        return s.num_powerset_classes if s.powerset else len(s.classes)
+
+    def _build_engine(self, device):
+        from .segmentation import SegmentationEngine
+        from .weights import SegmentationPack
+        s = self.specifications
+        if not s.powerset:
+            raise NotImplementedError("only powerset segmentation models are on the accelerated path")
+        pack = SegmentationPack(self._state_dict, dict(self.hparams), s.num_powerset_classes,
+                                len(s.classes), s.powerset_max_classes, device)
+        return SegmentationEngine(pack)
+
+    def __call__(self, waveforms: torch.Tensor) -> torch.Tensor:
+        """(batch, 1, samples) -> (batch, frames, classes) log-probabilities (PyanNet.py:211-240)."""
+        return self.engine.forward(waveforms)
+
+    forward = __call__
+
+
+class WeSpeakerResNet34(Model):
+    """models/embedding/wespeaker/__init__.py:346-372 over the HIP embedding engine."""
+
+    ARCHITECTURE = ("pyannote.audio.models.embedding.wespeaker", "WeSpeakerResNet34")
+
+    @property
+    def dimension(self) -> int:
+        return int(self._state_dict["resnet.seg_1.weight"].shape[0])
+
+    def num_frames(self, num_samples: int) -> int:
+        t = multi_conv_num_frames(num_samples, [400], [160], [0], [1])
+        for s in (1, 1, 2, 2, 2):  # conv1 + first conv of each layer (3x3, pad 1)
+            t = (t + 2 - 3) // s + 1
+        return t
+
+    def receptive_field_size(self, num_frames: int = 1) -> int:
+        ks, ss, ps = [3], [1], [1]
+        for n, s in zip((3, 4, 6, 3), (1, 2, 2, 2)):
+            for i in range(n):
+                ks += [3, 3]
+                ss += [s if i == 0 else 1, 1]
+                ps += [1, 1]
+        size = multi_conv_receptive_field_size(num_frames, ks, ss, ps, [1] * len(ks))
+        return multi_conv_receptive_field_size(size, [400], [160], [0], [1])
+
+    def receptive_field_center(self, frame: int = 0) -> int:
+        ks, ss, ps = [3], [1], [1]
+        for n, s in zip((3, 4, 6, 3), (1, 2, 2, 2)):
+            for i in range(n):
+                ks += [3, 3]
+                ss += [s if i == 0 else 1, 1]
+                ps += [1, 1]
+        c = multi_conv_receptive_field_center(frame, ks, ss, ps, [1] * len(ks))
+        return multi_conv_receptive_field_center(c, [400], [160], [0], [1])
+
+    def _build_engine(self, device):
+        from .embedding import EmbeddingEngine
+        from .weights import EmbeddingPack
+        return EmbeddingEngine(EmbeddingPack(self._state_dict, device,
+                                             sample_rate=self.audio.sample_rate))
+
+    def __call__(self, waveforms: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.engine.forward(waveforms, weights)
+
+    forward = __call__
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic checkpoints in the reference layout (no pretrained weights are available offline)
+# ---------------------------------------------------------------------------------------------
+def segmentation_specifications(duration: float = 10.0) -> Specifications:
+    """segmentation-3.0: powerset of 3 speakers, at most 2 simultaneously."""
+    return Specifications(problem=Problem.MONO_LABEL_CLASSIFICATION, resolution=Resolution.FRAME,
+                          duration=duration, min_duration=None, warm_up=(0.0, 0.0),
+                          classes=["speaker#1", "speaker#2", "speaker#3"], powerset_max_classes=2,
+                          permutation_invariant=True)
+
+
+def embedding_specifications() -> Specifications:
+    return Specifications(problem=Problem.REPRESENTATION, resolution=Resolution.CHUNK, duration=5.0)

@@ -1,0 +1,385 @@
+"""Pipeline base class: the plugin boundary b1 of SURVEY.md section 8b.
+
+Mirrors core/pipeline.py (from_pretrained :152-334, __setattr__ registry :362-400, __call__ :510-589,
+to :591-611) and the part of the third-party `pyannote.pipeline.Pipeline` it builds on (parameters,
+instantiate, freeze).  `config.yaml` files written for the reference load unchanged: the reference
+class path `pyannote.audio.pipelines.SpeakerDiarization` resolves to this package's implementation."""
+from __future__ import annotations
+
+import os
+import warnings
+from collections import OrderedDict
+from functools import partial
+from importlib import import_module
+from pathlib import Path
+from typing import Any, Callable, Iterator, Mapping, Optional
+
+import torch
+import yaml
+
+from .audio import Audio, AudioFile
+from .model import Model
+
+
+# ---------------------------------------------------------------------------------------------
+# hyper-parameter declarations (pyannote.pipeline.parameter)
+# ---------------------------------------------------------------------------------------------
+class Parameter:
+    pass
+
+
+class Uniform(Parameter):
+    def __init__(self, low: float, high: float):
+        self.low, self.high = float(low), float(high)
+
+
+class LogUniform(Uniform):
+    pass
+
+
+class Integer(Parameter):
+    def __init__(self, low: int, high: int):
+        self.low, self.high = int(low), int(high)
+
+
+class Categorical(Parameter):
+    def __init__(self, choices):
+        self.choices = list(choices)
+
+
+class ParamDict(Parameter):
+    def __init__(self, **params):
+        self.params = params
+
+
+class _Namespace(dict):
+    """instantiated ParamDict: values by attribute or key"""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class BaseInference:
+    """core/inference.py:42-43 marker: objects `Pipeline.to()` moves."""
+    pass
+
+
+def get_class_by_name(class_name: str, default_module_name: Optional[str] = None) -> type:
+    """pyannote.core.utils.helper.get_class_by_name + alias of the reference's own class paths."""
+    tokens = class_name.split(".")
+    if class_name.startswith("pyannote.audio.pipelines") and tokens[-1] == "SpeakerDiarization":
+        from .speaker_diarization import SpeakerDiarization
+        return SpeakerDiarization
+    if len(tokens) == 1:
+        if default_module_name is None:
+            raise ValueError(f"cannot resolve class {class_name!r} without a module name")
+        module_name = default_module_name
+    else:
+        module_name = ".".join(tokens[:-1])
+        class_name = tokens[-1]
+    return getattr(import_module(module_name), class_name)
+
+
+def expand_subfolders(config, model_id=None, parent_subfolder=None, parent_revision=None,
+                      cache_dir=None, token=None) -> None:
+    """core/pipeline.py:50-148: "$model/{subfolder}" -> {"checkpoint": model_id, "subfolder": ...}"""
+    def expand(value):
+        subfolder = "/".join(value.split("/")[1:])
+        if "@" in subfolder:
+            subfolder, revision = subfolder.split("@")
+        else:
+            revision = parent_revision
+        if parent_subfolder:
+            subfolder = f"{parent_subfolder.rstrip('/')}/{subfolder.lstrip('/')}"
+        return {"checkpoint": model_id, "revision": revision, "subfolder": subfolder, "token": token,
+                "cache_dir": cache_dir}
+
+    items = config.items() if isinstance(config, dict) else \
+        enumerate(config) if isinstance(config, list) else ()
+    for key, value in list(items):
+        if isinstance(value, str) and value.startswith("$model/"):
+            config[key] = expand(value)
+        else:
+            expand_subfolders(value, model_id, parent_subfolder=parent_subfolder,
+                              parent_revision=parent_revision, token=token, cache_dir=cache_dir)
+
+
+class Pipeline:
+    def __init__(self):
+        d = self.__dict__
+        d["_parameters"] = OrderedDict()
+        d["_instantiated"] = OrderedDict()
+        d["_frozen"] = OrderedDict()
+        d["_pipelines"] = OrderedDict()
+        d["_models"] = OrderedDict()
+        d["_inferences"] = OrderedDict()
+        d["training"] = False
+
+    # -- attribute registry (core/pipeline.py:340-409)
+    def __getattr__(self, name):
+        d = self.__dict__
+        for reg in ("_instantiated", "_parameters", "_pipelines", "_models", "_inferences"):
+            if reg in d and name in d[reg]:
+                return d[reg][name]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        regs = ("_parameters", "_instantiated", "_pipelines", "_models", "_inferences")
+
+        def remove_from(*which):
+            for r in which:
+                if r in d and name in d[r]:
+                    del d[r][name]
+            if name in d and name not in regs:
+                pass
+
+        if isinstance(value, Parameter):
+            if "_parameters" not in d:
+                raise AttributeError("cannot assign hyper-parameters before Pipeline.__init__() call")
+            remove_from(*regs)
+            d.pop(name, None)
+            d["_parameters"][name] = value
+            return
+        if isinstance(value, Pipeline):
+            if "_pipelines" not in d:
+                raise AttributeError("cannot assign sub-pipelines before Pipeline.__init__() call")
+            remove_from(*regs)
+            d.pop(name, None)
+            d["_pipelines"][name] = value
+            return
+        if isinstance(value, Model):
+            if "_models" not in d:
+                raise AttributeError("cannot assign models before Pipeline.__init__() call")
+            remove_from(*regs)
+            d.pop(name, None)
+            d["_models"][name] = value
+            return
+        if isinstance(value, BaseInference):
+            if "_inferences" not in d:
+                raise AttributeError("cannot assign inferences before Pipeline.__init__() call")
+            remove_from(*regs)
+            d.pop(name, None)
+            d["_inferences"][name] = value
+            return
+        object.__setattr__(self, name, value)
+
+    def __delattr__(self, name):
+        for reg in ("_models", "_inferences", "_parameters", "_instantiated", "_pipelines"):
+            if name in self.__dict__.get(reg, {}):
+                del self.__dict__[reg][name]
+                return
+        object.__delattr__(self, name)
+
+    # -- hyper-parameters (pyannote.pipeline.Pipeline)
+    def parameters(self, frozen: bool = False, instantiated: bool = False) -> dict:
+        out = {}
+        for name, p in self._parameters.items():
+            if instantiated:
+                if name in self._instantiated:
+                    out[name] = dict(self._instantiated[name]) \
+                        if isinstance(self._instantiated[name], dict) else self._instantiated[name]
+            else:
+                out[name] = p
+        for name, sub in self._pipelines.items():
+            out[name] = sub.parameters(frozen=frozen, instantiated=instantiated)
+        return out
+
+    @property
+    def instantiated(self) -> bool:
+        for name, p in self._parameters.items():
+            if name not in self._instantiated:
+                return False
+            if isinstance(p, ParamDict) and set(p.params) - set(self._instantiated[name]):
+                return False
+        return all(sub.instantiated for sub in self._pipelines.values())
+
+    def instantiate(self, params: Mapping) -> "Pipeline":
+        for name, value in params.items():
+            if name in self._pipelines:
+                self._pipelines[name].instantiate(value)
+            elif name in self._parameters:
+                p = self._parameters[name]
+                if isinstance(p, ParamDict):
+                    unknown = set(value) - set(p.params)
+                    if unknown:
+                        raise ValueError(f"parameter(s) {sorted(unknown)} do not exist for {name!r}")
+                    self._instantiated[name] = _Namespace(value)
+                else:
+                    self._instantiated[name] = value
+            else:
+                raise ValueError(f"parameter {name!r} does not exist")
+        self.initialize()
+        return self
+
+    def freeze(self, params: Mapping) -> "Pipeline":
+        self._frozen.update(params)
+        return self.instantiate(params)
+
+    def initialize(self):
+        pass
+
+    def load_params(self, params_yml) -> "Pipeline":
+        with open(params_yml, "r") as fp:
+            params = yaml.load(fp, Loader=yaml.SafeLoader)
+        return self.instantiate(params["params"])
+
+    def default_parameters(self):
+        raise NotImplementedError()
+
+    def classes(self):
+        raise NotImplementedError()
+
+    # -- loading (core/pipeline.py:152-334)
+    @classmethod
+    def from_pretrained(cls, checkpoint, revision: Optional[str] = None, hparams_file=None,
+                        subfolder: Optional[str] = None, token=None, cache_dir=None
+                        ) -> Optional["Pipeline"]:
+        if isinstance(checkpoint, dict):
+            if revision is not None:
+                raise ValueError("Revisions cannot be used with local checkpoints.")
+            if subfolder is not None:
+                raise ValueError("Subfolder cannot be used when checkpoint is a config dictionary. ")
+            model_id = Path.cwd()
+            config = checkpoint
+        elif os.path.isdir(checkpoint):
+            if revision is not None:
+                raise ValueError("Revisions cannot be used with local checkpoints.")
+            model_id = Path(checkpoint)
+            config_yml = model_id / subfolder / "config.yaml" if subfolder else model_id / "config.yaml"
+        elif os.path.isfile(checkpoint):
+            if revision is not None:
+                raise ValueError("Revisions cannot be used with local checkpoints.")
+            if subfolder is not None:
+                raise ValueError(
+                    "Subfolder cannot be used when checkpoint is a path to a config.yaml file. ")
+            model_id = Path(checkpoint).parent
+            config_yml = checkpoint
+        else:
+            if "@" in str(checkpoint):
+                raise ValueError("Revisions must be passed with `revision` keyword argument.")
+            # Hugging Face download is out of scope (no network): the reference returns None when
+            # the download fails (core/pipeline.py:237-238); so do we, after saying why.
+            warnings.warn(f"{checkpoint!s} is not a local path; downloading from the Hugging Face hub "
+                          "is not supported by this build.")
+            return None
+
+        if not isinstance(checkpoint, dict):
+            with open(config_yml, "r") as fp:
+                config = yaml.load(fp, Loader=yaml.SafeLoader)
+
+        expand_subfolders(config, str(model_id), parent_subfolder=subfolder, parent_revision=revision,
+                          token=token, cache_dir=cache_dir)
+        if "version" in config:
+            config["dependencies"] = {"pyannote.audio": config["version"]}
+            del config["version"]
+
+        pipeline_name = config["pipeline"]["name"]
+        Klass = get_class_by_name(pipeline_name, default_module_name="pyannote_audio_amd")
+        params = config["pipeline"].get("params", {})
+        params.setdefault("token", token)
+        params.setdefault("cache_dir", cache_dir)
+        pipeline = Klass(**params)
+
+        if "freeze" in config:
+            pipeline.freeze(config["freeze"])
+        if "params" in config:
+            pipeline.instantiate(config["params"])
+        if hparams_file is not None:
+            pipeline.load_params(hparams_file)
+        if "preprocessors" in config:
+            preprocessors = {}
+            for key, preprocessor in config.get("preprocessors", {}).items():
+                if isinstance(preprocessor, dict):
+                    K = get_class_by_name(preprocessor["name"], default_module_name="pyannote_audio_amd")
+                    preprocessors[key] = K(**preprocessor.get("params", {}))
+                else:
+                    preprocessors[key] = preprocessor
+            pipeline.preprocessors = preprocessors
+        if "device" in config:
+            try:
+                pipeline.to(torch.device(config["device"]))
+            except RuntimeError as e:
+                print(e)
+        return pipeline
+
+    # -- application (core/pipeline.py:411-589)
+    @staticmethod
+    def setup_hook(file: AudioFile, hook: Optional[Callable] = None) -> Callable:
+        def noop(*args, **kwargs):
+            return
+
+        return partial(hook or noop, file=file)
+
+    def prepare_one(self, file: AudioFile, preload: bool = False) -> Mapping:
+        file = Audio.validate_file(file)
+        if preload:
+            if "waveform" in file:
+                raise ValueError("Cannot preload audio: `waveform` key is already available or will "
+                                 "be via a preprocessor.")
+            file["waveform"], file["sample_rate"] = Audio()(file)
+            file.pop("channel", None)
+        return file
+
+    def _apply_batch(self, files: list, **kwargs) -> Iterator[tuple]:
+        if hasattr(self, "apply_batch"):
+            for f, prediction in self.apply_batch(files, **kwargs):
+                yield f, prediction
+        else:
+            for f in files:
+                yield f, self.apply(f, **f.get("pipeline_kwargs", {}), **kwargs)
+
+    def __call__(self, file, preload: bool = False, **kwargs) -> Any:
+        if not self.instantiated:
+            try:
+                default_parameters = self.default_parameters()
+            except NotImplementedError:
+                raise RuntimeError("A pipeline must be instantiated with "
+                                   "`pipeline.instantiate(parameters)` before it can be applied.")
+            try:
+                self.instantiate(default_parameters)
+            except ValueError:
+                raise RuntimeError(
+                    "A pipeline must be instantiated with `pipeline.instantiate(parameters)` before "
+                    "it can be applied. Tried to use parameters provided by "
+                    "`pipeline.default_parameters()` but those are not compatible. ")
+            warnings.warn(f"The pipeline has been automatically instantiated with {default_parameters}.")
+
+        if isinstance(file, list):
+            files = [self.prepare_one(f, preload=preload) for f in file]
+            uris = [f["uri"] for f in files]
+            if len(uris) != len(set(uris)):
+                seen: set = set()
+                duplicates = [u for u in uris if u in seen or seen.add(u)]
+                raise ValueError("All files in a batch must have distinct URIs. "
+                                 f"Duplicate URIs: {duplicates}")
+            return self._apply_batch(files, **kwargs)
+
+        file = self.prepare_one(file, preload=preload)
+        return self.apply(file, **file.get("pipeline_kwargs", {}), **kwargs)
+
+    def to(self, device: torch.device) -> "Pipeline":
+        if not isinstance(device, torch.device):
+            raise TypeError(
+                f"`device` must be an instance of `torch.device`, got `{type(device).__name__}`")
+        for _, pipeline in self._pipelines.items():
+            if hasattr(pipeline, "to"):
+                _ = pipeline.to(device)
+        for _, model in self._models.items():
+            _ = model.to(device)
+        for _, inference in self._inferences.items():
+            _ = inference.to(device)
+        self.device = device
+        return self
+
+    def cuda(self, device=None) -> "Pipeline":
+        if device is None:
+            return self.to(torch.device("cuda"))
+        if isinstance(device, int):
+            return self.to(torch.device("cuda", device))
+        if device.type != "cuda":
+            raise ValueError("Expected CUDA device. Use `Pipeline.to(device)` for other devices.")
+        return self.to(device)

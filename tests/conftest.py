@@ -37,3 +37,58 @@ def report(name, got, want, log=None):
         fp.write(line + "\n")
     print(line)
     return diff.max().item()
+
+
+PYANNET_HPARAMS = {
+    "sincnet": {"stride": 10, "sample_rate": 16000},
+    "lstm": {"hidden_size": 128, "num_layers": 4, "bidirectional": True, "monolithic": True,
+             "dropout": 0.0, "batch_first": True},
+    "linear": {"hidden_size": 128, "num_layers": 2},
+    "sample_rate": 16000, "num_channels": 1,
+}
+WESPEAKER_HPARAMS = {"sample_rate": 16000, "num_channels": 1, "num_mel_bins": 80, "frame_length": 25,
+                     "frame_shift": 10, "dither": 0.0, "window_type": "hamming", "use_energy": False}
+
+
+def write_pipeline_dir(root, seg_model, emb_model, config_extra=None):
+    """synthetic `speaker-diarization-3.1`-style directory: config.yaml + two reference-format
+    checkpoints under $model/segmentation and $model/embedding."""
+    import yaml
+    from pyannote_audio_amd.model import (PyanNet, WeSpeakerResNet34, embedding_specifications,
+                                          save_checkpoint, segmentation_specifications)
+    root = str(root)
+    os.makedirs(os.path.join(root, "segmentation"), exist_ok=True)
+    os.makedirs(os.path.join(root, "embedding"), exist_ok=True)
+    save_checkpoint(os.path.join(root, "segmentation", "pytorch_model.bin"), seg_model.state_dict(),
+                    PYANNET_HPARAMS, PyanNet.ARCHITECTURE, segmentation_specifications(10.0))
+    save_checkpoint(os.path.join(root, "embedding", "pytorch_model.bin"), emb_model.state_dict(),
+                    WESPEAKER_HPARAMS, WeSpeakerResNet34.ARCHITECTURE, embedding_specifications())
+    config = {
+        "version": "3.1.0",
+        "pipeline": {"name": "pyannote.audio.pipelines.SpeakerDiarization",
+                     "params": {"clustering": "AgglomerativeClustering",
+                                "embedding": "$model/embedding", "embedding_batch_size": 32,
+                                "embedding_exclude_overlap": True,
+                                "segmentation": "$model/segmentation", "segmentation_batch_size": 32}},
+        "params": {"clustering": {"method": "centroid", "min_cluster_size": 12,
+                                  "threshold": 0.7045654963945799},
+                   "segmentation": {"min_duration_off": 0.0}},
+    }
+    if config_extra:
+        config.update(config_extra)
+    with open(os.path.join(root, "config.yaml"), "w") as fp:
+        yaml.safe_dump(config, fp)
+    return os.path.join(root, "config.yaml")
+
+
+@pytest.fixture(scope="session")
+def synthetic_models():
+    from oracle.synthetic import calibrated_pyannet, calibrated_wespeaker
+    return calibrated_pyannet(calib_seconds=60.0), calibrated_wespeaker(calib_seconds=24.0)
+
+
+@pytest.fixture(scope="session")
+def pipeline_dir(tmp_path_factory, synthetic_models):
+    d = tmp_path_factory.mktemp("sd31")
+    write_pipeline_dir(d, *synthetic_models)
+    return str(d)

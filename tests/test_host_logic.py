@@ -1,0 +1,180 @@
+"""Host-side logic of the product (no GPU): overlap-add, counting, top-k discretisation, hysteresis,
+clustering, checkpoint + config loading, error behaviour -- each against the oracle's loop-for-loop
+restatement of the reference (oracle/pipeline.py) on seeded inputs.  Integer/index results bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import pyannote_audio_amd as pa
+from oracle import pipeline as O
+from pyannote_audio_amd import diarization as D
+from pyannote_audio_amd.core import SlidingWindow, SlidingWindowFeature
+from pyannote_audio_amd.inference import Inference
+
+
+def _random_segmentations(C=40, F=589, S=3, seed=0):
+    rng = np.random.default_rng(seed)
+    seg = np.zeros((C, F, S), dtype=np.float32)
+    for c in range(C):
+        for s in range(S):
+            pos = 0
+            while pos < F:
+                gap, on = int(rng.integers(5, 200)), int(rng.integers(5, 250))
+                if rng.uniform() < 0.6:
+                    seg[c, pos + gap: pos + gap + on, s] = 1.0
+                pos += gap + on
+    seg[(seg.sum(-1) > 2)] = 0  # at most 2 simultaneous (powerset 3/2)
+    return seg
+
+
+CHUNKS = SlidingWindow(start=0.0, duration=10.0, step=1.0)
+FRAMES = SlidingWindow(start=0.0, duration=991 / 16000, step=270 / 16000)
+OCH, OFR = O.SW(0.0, 10.0, 1.0), O.SW(0.0, 991 / 16000, 270 / 16000)
+
+
+def test_aggregate_and_count_match_oracle():
+    seg = _random_segmentations()
+    count = D.speaker_count(SlidingWindowFeature(seg, CHUNKS), FRAMES, warm_up=(0.0, 0.0))
+    ref, ref_frames = O.speaker_count(seg, OCH, OFR)
+    assert count.data.dtype == np.uint8 and np.array_equal(count.data, ref)
+    assert count.sliding_window.step == ref_frames.step
+    # 1 h geometry: 3591 chunks -> 213334 frames, last chunk at frame 212741
+    from pyannote_audio_amd.inference import aggregate_start_frames
+    st = aggregate_start_frames(SlidingWindow(start=0.0, duration=10.0, step=1.0), FRAMES, 3591)
+    assert st[-1] == 212741 and st[-1] + 589 + 4 == 213334
+    # generic float data + NaNs + hamming + warm-up
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((12, 589, 4)).astype(np.float32)
+    x[3, 100:200, 1] = np.nan
+    got = Inference.aggregate(SlidingWindowFeature(x.copy(), CHUNKS), FRAMES, warm_up=(0.1, 0.1),
+                              hamming=True, missing=0.0)
+    want, _ = O.aggregate(x.copy(), OCH, OFR, warm_up=(0.1, 0.1), hamming=True, missing=0.0)
+    assert np.array_equal(got.data, want)
+
+
+def test_reconstruct_and_binarize_match_oracle(monkeypatch):
+    seg = _random_segmentations(seed=3)
+    C = seg.shape[0]
+    rng = np.random.default_rng(4)
+    hard = rng.integers(0, 4, size=(C, 3))
+    hard[rng.uniform(size=hard.shape) < 0.15] = -2
+    count = D.speaker_count(SlidingWindowFeature(seg, CHUNKS), FRAMES, warm_up=(0.0, 0.0))
+    count.data = np.minimum(count.data, 3).astype(np.int8)
+    sd = pa.SpeakerDiarization.__new__(pa.SpeakerDiarization)
+    got = pa.SpeakerDiarization.reconstruct(sd, SlidingWindowFeature(seg, CHUNKS), hard.copy(), count)
+    want = O.reconstruct(seg, OCH, hard.copy(), count.data, OFR)
+    assert np.array_equal(got.data, want)
+    ann = D.to_annotation(got)
+    tracks = [(s.start, s.end, t, l) for s, t, l in ann.itertracks(yield_label=True)]
+    assert tracks == O.binarize(want, OFR)
+    assert ann.labels() == sorted({t[3] for t in tracks}, key=str)
+
+
+def _cluster_data(C=60, S=3, D_=32, K=4, seed=0):
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((K, D_))
+    who = rng.integers(0, K, size=(C, S))
+    emb = (centers[who] + 0.15 * rng.standard_normal((C, S, D_))).astype(np.float32)
+    emb[5, 1] = np.nan
+    seg = _random_segmentations(C=C, seed=seed + 1)
+    return emb, seg
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(num_clusters=3), dict(min_clusters=6), dict(max_clusters=2)])
+def test_clustering_matches_oracle(kw):
+    emb, seg = _cluster_data()
+    clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
+        {"method": "centroid", "min_cluster_size": 12, "threshold": 0.7045654963945799})
+    hard, soft, cen = clu(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS), **kw)
+    rh, rs, rc = O.clustering(emb.copy(), seg, **kw)
+    assert np.array_equal(hard, rh)
+    assert np.array_equal(cen, rc)
+    assert np.array_equal(soft, rs, equal_nan=True)
+
+
+def test_reference_clustering_kat_on_product_class():
+    """/root/reference/tests/test_clustering.py:6-29"""
+    embeddings = np.array([[1.0, 1.0, 1.0, 1.0], [1.0, 2.0, 1.0, 2.0]])
+    clustering = pa.AgglomerativeClustering().instantiate(
+        {"method": "centroid", "min_cluster_size": 0, "threshold": 0.0})
+    clusters = clustering.cluster(embeddings=embeddings, min_clusters=2, max_clusters=2, num_clusters=2)
+    assert np.array_equal(clusters, np.array([0, 1]))
+
+
+def test_checkpoint_roundtrip_and_layouts(tmp_path, synthetic_models):
+    from oracle.models import PyanNet as OPyanNet
+    from pyannote_audio_amd.model import (Model, PyanNet, save_checkpoint, segmentation_specifications)
+    from pyannote_audio_amd.weights import SegmentationPack
+    from conftest import PYANNET_HPARAMS
+    seg, _ = synthetic_models
+    p = tmp_path / "pytorch_model.bin"
+    save_checkpoint(p, seg.state_dict(), PYANNET_HPARAMS, PyanNet.ARCHITECTURE,
+                    segmentation_specifications())
+    m = Model.from_pretrained(str(tmp_path))
+    assert isinstance(m, PyanNet) and m.specifications.powerset and m.dimension == 7
+    assert m.specifications.num_powerset_classes == 7 and m.num_frames(160000) == 589
+    rf = m.receptive_field
+    assert (rf.start, round(rf.duration * 16000), round(rf.step * 16000)) == (0.0, 991, 270)
+    for k, v in seg.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v)
+    # non-monolithic LSTM key layout (PyanNet.py:101-123) packs to the same device images
+    mono = OPyanNet(lstm={"num_layers": 2})
+    split = OPyanNet(lstm={"num_layers": 2, "monolithic": False})
+    sd = dict(mono.state_dict())
+    sd2 = {k: v for k, v in sd.items() if not k.startswith("lstm.")}
+    for l in range(2):
+        for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            for suffix in ("", "_reverse"):
+                sd2[f"lstm.{l}.{name}_l0{suffix}"] = sd[f"lstm.{name}_l{l}{suffix}"]
+    assert set(sd2) == set(split.state_dict())
+    a = SegmentationPack(sd, {"lstm": {"num_layers": 2}}, 7, 3, 2, torch.device("cpu"))
+    b = SegmentationPack(sd2, {"lstm": {"num_layers": 2, "monolithic": False}}, 7, 3, 2,
+                         torch.device("cpu"))
+    assert all(torch.equal(x, y) for x, y in zip(a._keep, b._keep))
+
+
+def test_pipeline_from_pretrained_contract(pipeline_dir):
+    """plugin boundary b1 (cf. /root/reference/tests/test_pipeline_subfolder.py)."""
+    import os
+    p = pa.Pipeline.from_pretrained(pipeline_dir)
+    assert isinstance(p, pa.SpeakerDiarization)
+    assert p.instantiated and p.clustering.method == "centroid" and p.clustering.min_cluster_size == 12
+    assert p.clustering.threshold == 0.7045654963945799 and p.segmentation.min_duration_off == 0.0
+    assert p.embedding_exclude_overlap is True and p.embedding_batch_size == 32
+    assert p.segmentation_batch_size == 32
+    p.segmentation_batch_size = 256
+    assert p._segmentation.batch_size == 256
+    assert p._embedding.min_num_samples == 400 and p._embedding.dimension == 256
+    assert p._embedding.metric == "cosine" and p._embedding.sample_rate == 16000
+    assert p._segmentation.step == 1.0 and p._segmentation.duration == 10.0
+    # same thing from the config.yaml path and from a dict
+    assert isinstance(pa.Pipeline.from_pretrained(os.path.join(pipeline_dir, "config.yaml")),
+                      pa.SpeakerDiarization)
+    with pytest.raises(TypeError):
+        p.to("cuda")
+    with pytest.raises(ValueError):
+        pa.Pipeline.from_pretrained(pipeline_dir, revision="main")
+    wav = torch.zeros(1, 160000)
+    with pytest.raises(ValueError, match="distinct URIs"):
+        p([{"waveform": wav, "sample_rate": 16000, "uri": "a"},
+           {"waveform": wav, "sample_rate": 16000, "uri": "a"}])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU compute path"):
+            p({"waveform": wav, "sample_rate": 16000})
+
+
+def test_error_behaviour(synthetic_models, tmp_path):
+    from pyannote_audio_amd.model import PyanNet, segmentation_specifications
+    from conftest import PYANNET_HPARAMS
+    seg, emb = synthetic_models
+    m = PyanNet(seg.state_dict(), PYANNET_HPARAMS, segmentation_specifications())
+    with pytest.raises(ValueError, match="Step between consecutive chunks"):
+        Inference(m, duration=10.0, step=11.0)       # tests/inference_test.py:59-63
+    with pytest.raises(ValueError, match="clustering must be one of"):
+        pa.SpeakerDiarization(segmentation=m, embedding=m, clustering="Nope")
+    with pytest.raises(ValueError):
+        D.set_num_speakers(min_speakers=4, max_speakers=2)
+    assert D.set_num_speakers(num_speakers=3) == (3, 3, 3)
+    assert D.set_num_speakers() == (None, 1, np.inf)
+    with pytest.raises(TypeError):
+        Inference(m).to("cuda:0")

@@ -1,0 +1,104 @@
+"""GPU: full product pipeline (Pipeline.from_pretrained -> pipeline(audio)) vs the oracle's
+loop-for-loop restatement on the same synthetic conversation and the same synthetic checkpoints.
+Bar (BASELINE.json north_star): hard segmentations equal where the top-2 log-prob gap is safe, embeddings
+within float tolerance, cluster assignments and output segments identical."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pdist_cdist_bit_exact_vs_scipy(gpu_device):
+    from scipy.spatial.distance import cdist, pdist
+    from pyannote_audio_amd import distance
+    rng = np.random.default_rng(0)
+    for n, d in ((700, 256), (129, 37), (2, 256)):
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        got = distance.pdist_euclidean(X, device=gpu_device)
+        want = pdist(X, metric="euclidean")
+        assert got.dtype == np.float64 and np.array_equal(got, want), f"pdist {n}x{d}"
+    A = rng.standard_normal((900, 256)).astype(np.float32)
+    A[17] = np.nan
+    B = rng.standard_normal((5, 256)).astype(np.float32)
+    got = distance.cdist(A, B, metric="cosine", device=gpu_device)
+    want = cdist(A, B, metric="cosine")
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_clustering_on_gpu_matches_host(gpu_device):
+    import pyannote_audio_amd as pa
+    from pyannote_audio_amd.core import SlidingWindow, SlidingWindowFeature
+    from test_host_logic import _cluster_data, CHUNKS
+    emb, seg = _cluster_data(C=400, D_=256, K=5, seed=9)
+    params = {"method": "centroid", "min_cluster_size": 12, "threshold": 0.7045654963945799}
+    host = pa.AgglomerativeClustering().instantiate(params)
+    dev = pa.AgglomerativeClustering().instantiate(params).to(gpu_device)
+    a = host(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS))
+    b = dev(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[1], b[1], equal_nan=True)
+
+
+@pytest.mark.parametrize("seconds,seed", [(33.0, 5), (27.3, 8)])
+def test_full_pipeline_matches_oracle(pipeline_dir, synthetic_models, gpu_device, seconds, seed):
+    import pyannote_audio_amd as pa
+    from oracle.pipeline import diarize
+    from oracle.synthetic import synth_conversation
+    seg_o, emb_o = synthetic_models
+    wav, _ = synth_conversation(seconds, seed=seed)
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir)
+    pipeline.to(gpu_device)
+    steps = []
+    artifacts = {}
+
+    def hook(step, artifact, file=None, total=None, completed=None):
+        steps.append(step)
+        if artifact is not None and total is None:
+            artifacts[step] = artifact
+
+    out = pipeline({"waveform": wav, "sample_rate": 16000, "uri": "synth"}, hook=hook)
+    ref = diarize(seg_o, emb_o, wav, exclude_overlap=True)
+    assert isinstance(out, pa.DiarizeOutput)
+    for s in ("segmentation", "speaker_counting", "embeddings", "discrete_diarization"):
+        assert s in steps
+    seg = artifacts["segmentation"].data
+    assert seg.shape == ref.segmentations.shape
+    mism = int((seg != ref.segmentations).sum())
+    with open("gpurun_out/parity.log", "a") as fp:
+        fp.write(f"pipeline[{seconds}s]: segmentation mismatching frames = {mism} of {seg.size}\n")
+    assert mism == 0
+    assert np.array_equal(artifacts["speaker_counting"].data, ref.count)
+    e = report(f"pipeline_embeddings_{seconds}", torch.from_numpy(artifacts["embeddings"]),
+               torch.from_numpy(ref.embeddings))
+    assert e < 2e-4 * np.abs(ref.embeddings).max()
+    got = [(s.start, s.end, l) for s, _, l in out.speaker_diarization.itertracks(yield_label=True)]
+    assert got == ref.diarization
+    gotx = [(s.start, s.end, l)
+            for s, _, l in out.exclusive_speaker_diarization.itertracks(yield_label=True)]
+    assert gotx == ref.exclusive_diarization
+    assert out.speaker_embeddings.shape == ref.centroids.shape
+    assert np.allclose(out.speaker_embeddings, ref.centroids, rtol=1e-3, atol=1e-4)
+    ser = out.serialize()
+    assert set(ser) == {"diarization", "exclusive_diarization"}
+    # legacy=True returns the bare Annotation (speaker_diarization.py:626-627)
+    pipeline.legacy = True
+    ann = pipeline({"waveform": wav, "sample_rate": 16000, "uri": "synth"})
+    assert isinstance(ann, pa.Annotation) and ann.uri == "synth"
+    assert "SPEAKER synth 1" in ann.to_rttm()
+
+
+def test_silence_returns_empty(pipeline_dir, gpu_device):
+    """count == 0 everywhere -> early exit with empty annotations (speaker_diarization.py:617-629)."""
+    import pyannote_audio_amd as pa
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir).to(gpu_device)
+    seg = pipeline._segmentation
+    wav = torch.zeros(1, 16000 * 12)
+    # force the "no speaker" class by running on digital silence; if the synthetic model still fires,
+    # the test only checks types
+    out = pipeline({"waveform": wav, "sample_rate": 16000, "uri": "z"})
+    assert isinstance(out, pa.DiarizeOutput)
+    assert isinstance(out.speaker_diarization, pa.Annotation)
