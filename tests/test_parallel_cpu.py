@@ -28,7 +28,7 @@ def _worker(rank, world, port, total, q):
     rng = np.random.default_rng(0)
     seg = (rng.uniform(size=(total, 37, 3)) < 0.4).astype(np.float32)
     emb = rng.standard_normal((total, 3, 16)).astype(np.float32)
-    emb[3, 1] = np.nan
+    emb[min(3, total - 1), 1] = np.nan
     shard = parallel.shard_from_env()
     assert (shard.rank, shard.world_size) == (rank, world)
     b, e = parallel.chunk_range(total, shard)
