@@ -1,0 +1,274 @@
+#!/usr/bin/env python
+"""bench.py -- audio-hours/s of the speaker-diarization-3.1 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the whole pipeline (`Pipeline.__call__` -> sliding-window PyanNet
+segmentation -> speaker counting -> WeSpeaker ResNet34 embeddings -> agglomerative clustering ->
+reconstruction -> Annotation) over one synthetic 1-hour 16 kHz mono recording PER GPU, the waveform
+already resident in HBM when the timed region starts (BASELINE.json configs[3]; N > 1 is configs[4]'s
+"one file per GPU" sharding: every rank diarizes its own file, then ONE RCCL all-gather exchanges the
+per-chunk hard segmentations + embeddings of all files, weak scaling).
+
+Checkpoints are synthetic (no network): seeded weights in the reference's
+state-dict layout with an extreme-learning-machine read-out so that the segmentation actually tracks
+the synthetic speakers.  They are produced by the CPU oracle's torch modules (oracle/synthetic.py),
+saved in the reference checkpoint format and loaded by the product through `Pipeline.from_pretrained`;
+the oracle takes no part in the measured path.  The same oracle models run the `cpu_baseline` leg.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP events on the launch stream via the library's built-in profiler) and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+# kernels whose roofline is the f32 MFMA rate; everything else is priced against HBM bandwidth
+MFMA_KERNELS = {"k_conv3x3", "k_gemm_tn", "k_lstm_rec", "k_sinc_fir_pool", "k_conv5_pool"}
+
+
+def build_checkpoints(workdir: str):
+    """synthetic speaker-diarization-3.1 directory (config.yaml + 2 reference-format checkpoints)."""
+    from oracle.synthetic import calibrated_pyannet, calibrated_wespeaker
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import write_pipeline_dir
+    seg_o = calibrated_pyannet(calib_seconds=60.0)
+    emb_o = calibrated_wespeaker(calib_seconds=24.0)
+    write_pipeline_dir(workdir, seg_o, emb_o)
+    return seg_o, emb_o
+
+
+def synth_hour(hours: float, seed: int, device=None) -> torch.Tensor:
+    """(1, n) float32 synthetic 3-speaker conversation (harmonic "voices" with distinct pitch and
+    formant, random turn-taking with 25 % overlapped turns, light noise), synthesised on `device`.
+    Same recipe as oracle.synthetic.synth_conversation, vectorised so that an hour takes seconds."""
+    sr, S = 16000, 3
+    n = int(hours * 3600 * sr)
+    rng = np.random.default_rng(seed)
+    dev = device or torch.device("cpu")
+    t = torch.arange(n, dtype=torch.float64, device=dev) / sr
+    d2 = torch.zeros((S, n + 1), dtype=torch.float64, device=dev)
+    events = [[] for _ in range(S)]
+
+    def add(s, a, b):
+        a, b = max(0, a), min(n, b)
+        if b - a < 200:
+            return
+        k = min(400, (b - a) // 2)
+        events[s].append((a, b, k))
+
+    pos, dur = 0.0, n / sr
+    while pos < dur:
+        pos += rng.uniform(0.1, 1.2)
+        s = int(rng.integers(S))
+        d = rng.uniform(0.8, 4.0)
+        a, b = int(pos * sr), int((pos + d) * sr)
+        if a >= n:
+            break
+        add(s, a, b)
+        if rng.uniform() < 0.25:
+            s2 = (s + 1 + int(rng.integers(S - 1))) % S
+            a2 = a + (b - a) // 2
+            b2 = b + int(rng.uniform(0.3, 1.5) * sr)
+            add(s2, a2, b2)
+            pos = min(b2, n) / sr
+        else:
+            pos = min(b, n) / sr
+    wav = torch.zeros(n, dtype=torch.float64, device=dev)
+    for s in range(S):
+        ev = np.array(events[s], dtype=np.int64).reshape(-1, 3)
+        a, b, k = (torch.from_numpy(ev[:, i]).to(dev) for i in range(3))
+        inv = 1.0 / k.to(torch.float64)
+        # trapezoid envelopes as the double prefix sum of 4 impulses per turn
+        d2[s].index_add_(0, a, inv)
+        d2[s].index_add_(0, a + k, -inv)
+        d2[s].index_add_(0, b - k, -inv)
+        d2[s].index_add_(0, b, inv)
+        env = torch.cumsum(torch.cumsum(d2[s], 0), 0)[:n].clamp_(0.0, 1.0)
+        f0 = 95 + 55 * s + rng.uniform(-5, 5)
+        vib = 1 + 0.01 * torch.sin(2 * np.pi * 0.7 * t)
+        sig = torch.zeros_like(t)
+        for h in range(1, 14):
+            amp = (1.0 / h) * np.exp(-((f0 * h - (450 + 500 * s)) / 1000.0) ** 2)
+            sig += amp * torch.sin(2 * np.pi * f0 * h * t * vib + rng.uniform(0, 6.28))
+        sig *= 0.6 + 0.4 * torch.sin(2 * np.pi * (3 + s) * t)
+        sig /= sig.abs().max()
+        wav += 0.3 * sig * env
+    g = torch.Generator(device=dev).manual_seed(seed)
+    wav += 0.003 * torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    return wav.clamp_(-1, 1).to(torch.float32)[None]
+
+
+class StageTimer:
+    """wall-clock per pipeline stage from the reference's hook protocol (TimingHook semantics)."""
+
+    def __init__(self):
+        self.t = {}
+        self._last = None
+
+    def start(self):
+        self._last = time.perf_counter()
+        self.t = {}
+
+    def __call__(self, step, artifact, file=None, total=None, completed=None):
+        if total is not None:   # progress callbacks
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.t[step] = self.t.get(step, 0.0) + now - self._last
+        self._last = now
+
+
+def cpu_baseline(seg_o, emb_o, seconds: float):
+    """the CPU oracle (reference algorithm, reference batching: 32/32, 3 backbone passes per chunk)
+    on a bounded sample, on the host cores of this box."""
+    from oracle.pipeline import diarize
+    from oracle.synthetic import synth_conversation
+    wav, _ = synth_conversation(seconds, seed=77)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.perf_counter()
+    out = diarize(seg_o, emb_o, wav, exclude_overlap=True)
+    dt = time.perf_counter() - t0
+    return {"value": (seconds / 3600.0) / dt, "unit": "audio-hours/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{seconds:.0f} s synthetic conversation, full pipeline, "
+            f"{dt:.1f} s wall", "stages_s": {k: round(v, 3) for k, v in out.timings.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--hours", type=float, default=1.0, help="audio hours per GPU and step")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of the CPU baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import pyannote_audio_amd as pa
+    import pyannote_audio_amd.ffi as ffi
+    ffi.require_gpu()
+
+    workdir = tempfile.mkdtemp(prefix=f"pa_bench_r{rank}_")
+    seg_o, emb_o = build_checkpoints(workdir)
+    pipeline = pa.Pipeline.from_pretrained(workdir)
+    pipeline.to(device)
+
+    wav = synth_hour(args.hours, seed=rank, device=device)      # resident in HBM before timing
+    file = {"waveform": wav, "sample_rate": 16000, "uri": f"synthetic_{rank}"}
+    timer = StageTimer()
+
+    def step():
+        timer.start()
+        out = pipeline(file, hook=timer)
+        if world > 1:
+            # exchange step of configs[4]: per-chunk hard segmentations + embeddings of every file
+            payload = pipeline.last_exchange_payload(device)
+            gathered = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=device)
+            dist.all_gather_into_tensor(gathered, payload)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stage_sum = {}
+    for _ in range(args.steps):
+        out = step()
+        for k, v in timer.t.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel timing of one extra (untimed) step: HIP events on the launch stream
+    ffi.prof_enable(True)
+    step()
+    torch.cuda.synchronize()
+    prof = ffi.prof_report()
+    ffi.prof_enable(False)
+
+    if rank == 0:
+        kernels = {}
+        for name, r in prof.items():
+            ms = r["ms"]
+            kernels[name] = {"launches": r["launches"], "ms": round(ms, 3),
+                             "tflops": round(r["flops"] / ms / 1e9, 2) if ms > 0 else None,
+                             "gbs": round(r["bytes"] / ms / 1e6, 1) if ms > 0 else None}
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        r = prof[dom]
+        if dom in MFMA_KERNELS:
+            ach = r["flops"] / r["ms"] / 1e9
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
+                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4),
+                    "algorithmic_gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3)}
+        else:
+            ach = r["bytes"] / r["ms"] / 1e6
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                    "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4)}
+        total_hours = args.hours * world * args.steps
+        line = {
+            "metric": "audio-hours/sec (real-time factor) for speaker-diarization-3.1 pipeline",
+            "value": round(total_hours / elapsed, 5), "unit": "audio-hours/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full speaker-diarization-3.1 pipeline (PyanNet 10 s / 1 s sliding "
+                                   "window, WeSpeaker ResNet34 embeddings, centroid AHC) on "
+                                   f"{args.hours:g} h of 16 kHz mono audio per GPU",
+                       "chunks_per_file": int((wav.shape[1] - 160000) // 16000 + 1),
+                       "files": world, "parallelism": f"file-per-gpu x{world}"},
+            "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
+            "stages_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage_sum.items()},
+            "speakers": len(out.speaker_diarization.labels()),
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(seg_o, emb_o, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,13 @@ extern "C" {
 int pa_version(void);
 const char* pa_last_error(void);
 
+/* Built-in kernel profiler (measurement aid, no reference counterpart): while enabled every launcher
+ * brackets its kernel with two hipEvents on the launch stream.  pa_prof_report synchronises and writes
+ * a JSON object {"kernel": {"launches", "ms", "flops", "bytes"}} (algorithmic flops/bytes) into buf,
+ * clears the records and returns the size needed. */
+void pa_prof_enable(int on);
+size_t pa_prof_report(char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * Segmentation model: replaces PyanNet.forward (models/segmentation/PyanNet.py:211-240) +
  * Powerset.to_multilabel(hard) (utils/powerset.py:115-140) as called from Inference.infer

@@ -43,7 +43,11 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
                 src.stat().st_mtime, *(h.stat().st_mtime for h in CSRC.glob("*.h")),
                 (PKG_DIR.parent / "include" / "pyannote_amd.h").stat().st_mtime):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+        extra = []
+        for line in src.read_text().splitlines():
+            if line.startswith("// hipcc-flags:"):
+                extra += line.split(":", 1)[1].split()
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *extra,
                "-I", str(PKG_DIR.parent / "include"), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))

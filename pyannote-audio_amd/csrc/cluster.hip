@@ -5,9 +5,16 @@
 // Bit-exactness contract: SciPy accumulates sum_k (u_k - v_k)^2 (resp. sum_k u_k v_k) sequentially in
 // k, in double, with separately rounded multiply and add (its x86-64 baseline build has no FMA).  The
 // kernels below keep one accumulator per output pair, walk k in ascending order and use
-// __dmul_rn/__dadd_rn so that the compiler cannot contract to FMA.  HBM-bound on the condensed
+// plain operators under `#pragma clang fp contract(off)` (HIP's __dmul_rn/__dadd_rn are ordinary
+// operators defined in a header, which the default -ffp-contract=fast still fuses).  HBM-bound on the condensed
 // output for large N (8 B per pair); the arithmetic (3 flop per pair and k) is far from the fp64 peak.
 #include "common.h"
+
+// hipcc's default -ffp-contract=fast fuses a*b+c to FMA and IGNORES `#pragma clang fp contract`;
+// __dmul_rn/__dadd_rn are plain operators in HIP headers and fuse as well.  This translation unit is
+// therefore compiled with -ffp-contract=off (the marker below is read by _build.py); verified in the
+// ISA: the k-loops hold v_mul_f64 + v_add_f64 only (v_fma_f64 remains inside sqrt/div expansions).
+// hipcc-flags: -ffp-contract=off
 
 namespace pa {
 
@@ -49,8 +56,8 @@ __global__ __launch_bounds__(256) void k_pdist_f64(const double* __restrict__ X,
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const double d = __dsub_rn(av[a], bv[b]);
-          acc[a][b] = __dadd_rn(acc[a][b], __dmul_rn(d, d));
+          const double d = av[a] - bv[b];
+          acc[a][b] = acc[a][b] + d * d;  // separately rounded (contract(off))
         }
     }
   }
@@ -70,7 +77,7 @@ __global__ void k_row_norms_f64(const double* __restrict__ X, int N, int D, doub
   double s = 0.0;
   for (int k = 0; k < D; ++k) {
     const double v = X[(long)i * D + k];
-    s = __dadd_rn(s, __dmul_rn(v, v));
+    s = s + v * v;
   }
   nrm[i] = __dsqrt_rn(s);
 }
@@ -89,10 +96,10 @@ __global__ __launch_bounds__(128) void k_cdist_cosine_f64(const double* __restri
   for (int j = threadIdx.x; j < NB; j += 128) {
     const double* v = B + (long)j * D;
     double s = 0.0;
-    for (int k = 0; k < D; ++k) s = __dadd_rn(s, __dmul_rn(us[k], v[k]));
-    double c = __ddiv_rn(s, __dmul_rn(na, nB[j]));
+    for (int k = 0; k < D; ++k) s = s + us[k] * v[k];
+    double c = s / (na * nB[j]);
     if (fabs(c) > 1.0) c = copysign(1.0, c);
-    out[(long)i * NB + j] = __dsub_rn(1.0, c);
+    out[(long)i * NB + j] = 1.0 - c;
   }
 }
 
@@ -104,6 +111,7 @@ extern "C" {
 int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream) {
   if (N < 2) return 0;
   const int nt = pa::cdiv(N, pa::PD_T);
+  pa::ProfScope prof("k_pdist_f64", stream, 3.0 * D * ((double)N * (N - 1) / 2), 8.0 * ((double)N * D + (double)N * (N - 1) / 2));
   hipLaunchKernelGGL(pa::k_pdist_f64, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, X, N, D, out);
   PA_CHECK_LAUNCH("pa_pdist_f64");
   return 0;
@@ -114,6 +122,7 @@ int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D,
                         double* norms, void* stream) {
   if (NA <= 0 || NB <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  pa::ProfScope prof("k_cdist_cosine_f64", stream, 2.0 * D * (double)NA * NB, 8.0 * ((double)NA * D + (double)NB * D + (double)NA * NB));
   hipLaunchKernelGGL(pa::k_row_norms_f64, dim3(pa::cdiv(NA, 128)), dim3(128), 0, st, A, NA, D, norms);
   hipLaunchKernelGGL(pa::k_row_norms_f64, dim3(pa::cdiv(NB, 128)), dim3(128), 0, st, B, NB, D,
                      norms + NA);

@@ -19,6 +19,15 @@ namespace pa {
 
 void set_error(const char* fmt, ...);
 
+// HIP-event profiler scope (pa_core.cpp): brackets the launches issued while it is alive with two
+// events on `stream`; `flops` / `bytes` are the ALGORITHMIC work of those launches.
+struct ProfScope {
+  ProfScope(const char* name, void* stream, double flops, double bytes);
+  ~ProfScope();
+  long idx_;
+  void* stream_;
+};
+
 #define PA_CHECK_LAUNCH(name)                                              \
   do {                                                                     \
     hipError_t e__ = hipGetLastError();                                    \

@@ -178,6 +178,8 @@ int pa_fbank(const float* wav, long wav_len, long chunk_stride, int B, int N, co
   PA_REQUIRE(N >= pa::FB_WIN, "pa_fbank: %d samples is shorter than one 25 ms frame", N);
   const int T = 1 + (N - pa::FB_WIN) / pa::FB_SHIFT;
   hipStream_t st = (hipStream_t)stream;
+  pa::ProfScope prof("k_fbank", stream, (double)B * T * (5.0 * 512 * 9 + 2.0 * 257 * 3 + 2.0 * 257 * 2),
+                     4.0 * B * N + 4.0 * B * T * nmel * (center ? 3 : 1));
   hipLaunchKernelGGL(pa::k_fbank, dim3(pa::cdiv(T, pa::FB_FPB), B), dim3(256), 0, st, wav, wav_len,
                      chunk_stride, T, 32768.0f, 0.97f, window, (const float2*)tw256,
                      (const float2*)tw512, mel_w, mel_lo, mel_hi, nmel, 1.1920928955078125e-07f, out);

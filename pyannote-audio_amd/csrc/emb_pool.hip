@@ -88,6 +88,7 @@ int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* 
   PA_REQUIRE(S >= 1 && S <= pa::POOL_MAXS && Tp <= pa::POOL_MAXT,
              "pa_stats_pool: S <= %d and T' <= %d required (got %d, %d)", pa::POOL_MAXS,
              pa::POOL_MAXT, S, Tp);
+  pa::ProfScope prof("k_stats_pool", stream, 6.0 * B * S * C * Fh * Tp, 4.0 * B * C * Fh * Tp + 8.0 * B * S * C * Fh);
   hipLaunchKernelGGL(pa::k_stats_pool, dim3(pa::cdiv(C, 256), Fh, B), dim3(256), 0,
                      (hipStream_t)stream, feat, Fh, Tp, C, masks, S, Fm, nearest_idx, stats);
   PA_CHECK_LAUNCH("pa_stats_pool");

@@ -241,6 +241,7 @@ extern "C" {
 int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, const float* shift,
                    float* out, void* stream) {
   if (B <= 0) return 0;
+  pa::ProfScope prof("k_stem", stream, 2.0 * B * T * F * 9 * 32, 4.0 * B * T * F * 33);
   hipLaunchKernelGGL(pa::k_stem, dim3(pa::cdiv(T, 64), F, B), dim3(256), 0, (hipStream_t)stream, fbank,
                      T, F, w9, shift, out);
   PA_CHECK_LAUNCH("pa_resnet_stem");
@@ -253,7 +254,10 @@ int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, co
   if (B <= 0) return 0;
   PA_REQUIRE(cin % pa::CB == 0 && cout % 32 == 0, "pa_conv3x3: cin %% 16 and cout %% 32 required");
   hipStream_t st = (hipStream_t)stream;
-  const int Ho = (H - 1) / stride + 1;
+  const int Ho = (H - 1) / stride + 1, Wo_ = (W - 1) / stride + 1;
+  // algorithmic work: 2*9*cin*cout per output pixel; bytes: input + output (+ residual) + weights once
+  pa::ProfScope prof("k_conv3x3", stream, 2.0 * 9 * cin * cout * (double)B * Ho * Wo_,
+                     4.0 * ((double)B * H * W * cin + (double)B * Ho * Wo_ * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   if (stride == 1) {
     if (cout == 32) pa::launch_conv<1, 8, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else if (Ho >= 32) pa::launch_conv<1, 8, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
@@ -275,6 +279,7 @@ int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* str
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long total4 = (long)B * Ho * Wo * (C / 4);
   if (total4 <= 0) return 0;
+  pa::ProfScope prof("k_gather_s2", stream, 0.0, 32.0 * total4);
   hipLaunchKernelGGL(pa::k_gather_s2, dim3(pa::cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, X,
                      H, W, C / 4, Ho, Wo, total4, A);
   PA_CHECK_LAUNCH("pa_gather_s2");

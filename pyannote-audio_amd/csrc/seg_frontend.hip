@@ -232,6 +232,7 @@ extern "C" {
 int pa_row_stats(const float* x, long row_stride, long total_len, int rows, int len, float eps,
                  float* mean, float* rstd, void* stream) {
   if (rows <= 0) return 0;
+  pa::ProfScope prof("k_row_stats", stream, 5.0 * rows * len, 8.0 * rows * len);
   hipLaunchKernelGGL(pa::k_row_stats, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, row_stride,
                      total_len, len, eps, mean, rstd);
   PA_CHECK_LAUNCH("pa_row_stats");
@@ -252,6 +253,8 @@ int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, i
                         (int)lds);
     attr = true;
   }
+  pa::ProfScope prof("k_sinc_fir_pool", stream, 2.0 * B * 80 * 251 * (3.0 * P),
+                     4.0 * B * N + 4.0 * B * 80 * P);
   hipLaunchKernelGGL(pa::k_sinc_fir_pool, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(320), lds,
                      (hipStream_t)stream, wav, wav_len, chunk_stride, N, stride, P, mean, rstd, gamma,
                      beta, filt_packed, out);
@@ -265,6 +268,8 @@ int pa_conv5_pool(const float* xin, int B, int cin, int Lin, const float* in_mea
   const int P = (Lin - 4) / 3;
   if (B <= 0 || P <= 0) return 0;
   dim3 grid(pa::cdiv(P, pa::CV_PT), B);
+  pa::ProfScope prof("k_conv5_pool", stream, 2.0 * B * 60 * cin * 5 * (3.0 * P),
+                     4.0 * B * cin * Lin + 4.0 * B * 60 * P);
   if (cin == 80)
     hipLaunchKernelGGL(pa::k_conv5_pool<80>, grid, dim3(256), 0, (hipStream_t)stream, xin, Lin, P,
                        in_mean, in_rstd, gam, bet, w_packed, bias64, out);
@@ -281,6 +286,7 @@ int pa_norm_transpose(const float* xin, int B, int T, const float* in_mean, cons
                       const float* gam, const float* bet, float* X0, void* stream) {
   if (B <= 0) return 0;
   const int ntiles = (B + 15) / 16;
+  pa::ProfScope prof("k_norm_transpose", stream, 4.0 * B * 60 * T, 4.0 * B * 60 * T + 4.0 * ntiles * 16 * 64 * T);
   hipLaunchKernelGGL(pa::k_norm_transpose, dim3(pa::cdiv(T, 64), ntiles * 16), dim3(256), 0,
                      (hipStream_t)stream, xin, B, T, in_mean, in_rstd, gam, bet, X0);
   PA_CHECK_LAUNCH("pa_norm_transpose");

@@ -296,6 +296,7 @@ int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bi
   const int nm = pa::cdiv(M, pa::GB), nn = pa::cdiv(N, pa::GB);
   const int grid = nn == 8 ? pa::cdiv(nm, 8) * 64 : nm * nn;
   hipStream_t st = (hipStream_t)stream;
+  pa::ProfScope prof("k_gemm_tn", stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define PA_GEMM(ACT, OM)                                                                          \
   hipLaunchKernelGGL((pa::k_gemm_tn<ACT, OM>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, \
                      C, ldc, M, N, K, nm, nn)
@@ -311,6 +312,10 @@ int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bi
 int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T,
                 void* stream) {
   if (ntiles <= 0 || T <= 0) return 0;
+  // algorithmic: h_{t-1} (16x128) x W_hh^T (128x512) per tile, direction and step + 512 gate inputs in,
+  // 128 outputs out per (chunk, step, direction)
+  pa::ProfScope prof("k_lstm_rec", stream, 2.0 * ntiles * 16 * ndir * T * 128 * 512,
+                     4.0 * ntiles * 16 * ndir * T * (512 + 128));
   hipLaunchKernelGGL(pa::k_lstm_rec, dim3(ntiles, ndir), dim3(256), 0, (hipStream_t)stream, xproj,
                      whh_packed, out, T);
   PA_CHECK_LAUNCH("pa_lstm_rec");
@@ -324,6 +329,7 @@ int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, cons
   const long M = (long)ntiles * T * 16;
   if (M <= 0) return 0;
   const size_t lds = (size_t)(NC * K + NC) * sizeof(float);
+  pa::ProfScope prof("k_classifier", stream, 2.0 * M * K * NC, 4.0 * M * K + 4.0 * M * NC);
   hipLaunchKernelGGL(pa::k_classifier, dim3(pa::cdiv(M, 256)), dim3(256), lds, (hipStream_t)stream, X,
                      ldx, K, (int)M, T, B, cw, cb, NC, mapping, S, logp, multilabel);
   PA_CHECK_LAUNCH("pa_classifier");

@@ -88,6 +88,10 @@ def load():
     lib.pa_lstm_rec.argtypes = [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]
     lib.pa_classifier.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp,
                                   C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]
+    lib.pa_prof_enable.argtypes = [C.c_int]
+    lib.pa_prof_enable.restype = None
+    lib.pa_prof_report.argtypes = [C.c_char_p, C.c_size_t]
+    lib.pa_prof_report.restype = C.c_size_t
     _declare_optional(lib)
     _LIB = lib
     return lib
@@ -147,6 +151,19 @@ def check(rc: int, what: str = ""):
     if rc == 3:
         raise ValueError(f"{what}: {msg}")
     raise RuntimeError(f"{what}: {msg}")
+
+
+def prof_enable(on: bool = True):
+    load().pa_prof_enable(1 if on else 0)
+
+
+def prof_report() -> dict:
+    """per-kernel {"launches", "ms", "flops", "bytes"} since the last report (HIP events on the
+    launch stream; algorithmic flops / bytes as declared by each launcher)."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    load().pa_prof_report(buf, len(buf))
+    return json.loads(buf.value.decode() or "{}")
 
 
 def require_gpu():

@@ -171,10 +171,21 @@ class SpeakerDiarization(Pipeline):
         wav = waveform.to(device, torch.float32).contiguous().view(-1)
         engine = self._embedding.model_.engine
         emb = engine.forward_strided(wav[begin * step:], step, num_chunks, window, masks)
+        self._last_exchange = (dev_bin, emb)
         embeddings = emb.cpu().numpy()
         if hook is not None:
             hook("embeddings", embeddings, total=batch_count, completed=batch_count)
         return embeddings
+
+    def last_exchange_payload(self, device: torch.device) -> torch.Tensor:
+        """Device-resident fused byte records of the last file's per-chunk results -- uint8 hard
+        segmentation (F*S bytes) followed by the fp32 embeddings (S*D*4 bytes) per chunk -- i.e. the
+        send buffer of the multi-file all-gather (parallel.all_gather_chunks uses the same record)."""
+        seg, emb = self._last_exchange
+        C = seg.shape[0]
+        seg_b = seg.to(torch.uint8).reshape(C, -1)
+        emb_b = emb.contiguous().view(torch.uint8).reshape(C, -1)
+        return torch.cat([seg_b, emb_b], dim=1).contiguous()
 
     def reconstruct(self, segmentations: SlidingWindowFeature, hard_clusters: np.ndarray,
                     count: SlidingWindowFeature) -> SlidingWindowFeature:

@@ -58,7 +58,8 @@ def test_full_pipeline_matches_oracle(pipeline_dir, synthetic_models, gpu_device
     def hook(step, artifact, file=None, total=None, completed=None):
         steps.append(step)
         if artifact is not None and total is None:
-            artifacts[step] = artifact
+            import copy
+            artifacts[step] = copy.deepcopy(artifact)   # `count.data` is re-assigned later (as in the reference)
 
     out = pipeline({"waveform": wav, "sample_rate": 16000, "uri": "synth"}, hook=hook)
     ref = diarize(seg_o, emb_o, wav, exclude_overlap=True)
