@@ -174,6 +174,36 @@ int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream);
 int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D, double* out,
                         double* norms, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Frame-domain stages (uint8 hard segmentations in, per-frame decisions out).  Replace the Python
+ * loops of Inference.aggregate (core/inference.py:589-611), speaker_count
+ * (pipelines/utils/diarization.py:150-185), SpeakerDiarization.reconstruct
+ * (pipelines/speaker_diarization.py:480-528), to_diarization (pipelines/utils/diarization.py:
+ * 221-268) and the numpy reductions of filter_embeddings (pipelines/clustering.py:109-116) and
+ * get_embeddings' mask selection (pipelines/speaker_diarization.py:375-427).
+ * seg: (C, F, S) uint8 {0,1};  start_frame: (C) int32 = closest_frame(chunk.start + frame.duration/2)
+ * (core/inference.py:596), computed by the caller in float64 exactly as the reference does.
+ * ---------------------------------------------------------------------------------------- */
+/* active[c][s] = sum_f seg;  clean[c][s] = sum_f seg * [sum_s' seg == 1]   (both (C,S) int32) */
+int pa_seg_chunk_stats(const uint8_t* seg, int C, int F, int S, int32_t* active, int32_t* clean,
+                       void* stream);
+/* masks (C,S,F) fp32: the overlap-free mask where exclude_overlap && clean[c][s] > min_num_frames,
+ * the full mask otherwise */
+int pa_embedding_masks(const uint8_t* seg, int C, int F, int S, const int32_t* clean,
+                       int exclude_overlap, int min_num_frames, float* masks, void* stream);
+/* count (T) uint8 = rint( overlap-add average of sum_s seg );  scratch: 2*T int32 */
+int pa_speaker_count(const uint8_t* seg, int C, int F, int S, const int32_t* start_frame, int T,
+                     uint8_t* count, int32_t* scratch, void* stream);
+/* act (T,K) int32 = overlap-add SUM over chunks of max_{s: hard[c][s]==k} seg[c][f][s];
+ * hard: (C,S) int32, negative = unassigned / inactive */
+int pa_cluster_activations(const uint8_t* seg, int C, int F, int S, const int32_t* start_frame,
+                           const int32_t* hard, int K, int T, int32_t* act, void* stream);
+/* out (T,K) uint8: the min(count[t], cap, K) most active clusters per frame, ties to the lowest index;
+ * tie (T) uint8: 1 where equal activations straddle the selection boundary (the reference's
+ * np.argsort order among equals is host-dependent: the caller re-decides those frames with numpy) */
+int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
+                     uint8_t* tie, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,13 +48,17 @@ class BaseClustering(Pipeline):
         return num_clusters, min_clusters, max_clusters
 
     def filter_embeddings(self, embeddings: np.ndarray, segmentations: SlidingWindowFeature,
-                          min_active_ratio: float = 0.2):
+                          min_active_ratio: float = 0.2, num_clean_frames: Optional[np.ndarray] = None):
         """clustering.py:77-125: keep (chunk, speaker) pairs that speak alone for >= 20 % of the chunk
-        and whose embedding is finite."""
+        and whose embedding is finite.  `num_clean_frames` (C, S): the per-(chunk, speaker) count of
+        single-speaker frames when the caller already has it (pa_seg_chunk_stats on the GPU)."""
         seg = segmentations.data
         _, num_frames, _ = seg.shape
-        single = np.sum(seg, axis=2, keepdims=True) == 1
-        num_clean = np.sum(seg * single, axis=1)
+        if num_clean_frames is not None:
+            num_clean = num_clean_frames
+        else:
+            single = np.sum(seg, axis=2, keepdims=True) == 1
+            num_clean = np.sum(seg * single, axis=1)
         active = num_clean >= min_active_ratio * num_frames
         valid = ~np.any(np.isnan(embeddings), axis=2)
         chunk_idx, speaker_idx = np.where(active * valid)
@@ -91,7 +95,8 @@ class BaseClustering(Pipeline):
                  max_clusters: Optional[int] = None, **kwargs):
         """clustering.py:214-289"""
         train_embeddings, train_chunk_idx, train_speaker_idx = self.filter_embeddings(
-            embeddings, segmentations=segmentations)
+            embeddings, segmentations=segmentations,
+            num_clean_frames=kwargs.get("num_clean_frames", None))
         num_embeddings, _ = train_embeddings.shape
         num_clusters, min_clusters, max_clusters = self.set_num_clusters(
             num_embeddings, num_clusters=num_clusters, min_clusters=min_clusters,

@@ -71,15 +71,27 @@ __global__ __launch_bounds__(256) void k_pdist_f64(const double* __restrict__ X,
     }
 }
 
+// SciPy's cdist "cosine" kernels (distance_impl.h: dot_product / _row_norms) are compiled 2-way
+// vectorised in the x86-64 wheel (SSE2, two doubles per register): even and odd k accumulate
+// separately, the two lanes are added, then an odd tail element is added last.  Pinned against
+// scipy 1.15.3 for even and odd D (tools/diag_pdist.py, tests/test_pipeline_gpu.py).
+__device__ __forceinline__ double dot2way(const double* __restrict__ u, const double* __restrict__ v,
+                                          int D) {
+  double s0 = 0.0, s1 = 0.0;
+  const int m = D & ~1;
+  for (int k = 0; k < m; k += 2) {
+    s0 = s0 + u[k] * v[k];
+    s1 = s1 + u[k + 1] * v[k + 1];
+  }
+  double t = s0 + s1;
+  if (D & 1) t = t + u[D - 1] * v[D - 1];
+  return t;
+}
+
 __global__ void k_row_norms_f64(const double* __restrict__ X, int N, int D, double* __restrict__ nrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  double s = 0.0;
-  for (int k = 0; k < D; ++k) {
-    const double v = X[(long)i * D + k];
-    s = s + v * v;
-  }
-  nrm[i] = __dsqrt_rn(s);
+  nrm[i] = __dsqrt_rn(dot2way(X + (long)i * D, X + (long)i * D, D));
 }
 
 // out[i][j] = 1 - clip(<a_i, b_j> / (|a_i| |b_j|));  grid = NA, block = 128 (threads stride over j)
@@ -94,9 +106,7 @@ __global__ __launch_bounds__(128) void k_cdist_cosine_f64(const double* __restri
   __syncthreads();
   const double na = nA[i];
   for (int j = threadIdx.x; j < NB; j += 128) {
-    const double* v = B + (long)j * D;
-    double s = 0.0;
-    for (int k = 0; k < D; ++k) s = s + us[k] * v[k];
+    const double s = dot2way(us, B + (long)j * D, D);
     double c = s / (na * nB[j]);
     if (fabs(c) > 1.0) c = copysign(1.0, c);
     out[(long)i * NB + j] = 1.0 - c;

@@ -7,6 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // D(16x16) += A(16x4) * B(4x16);  lane l supplies A[l&15][l>>4], B[l>>4][l&15];
 // D: lane l holds column l&15, rows 4*(l>>4)+r, r = 0..3.

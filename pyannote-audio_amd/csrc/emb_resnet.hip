@@ -84,7 +84,7 @@ struct ConvGeom {
 };
 
 template <int S, int TH, int TWT, int BN>
-__global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ X, int H, int W, int CIN,
+__global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X, int H, int W, int CIN,
                                                  const float* __restrict__ Wg,
                                                  const float* __restrict__ shift,
                                                  const float* __restrict__ R, float* __restrict__ Y,
@@ -113,33 +113,70 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ X, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const long xb = (long)b * H * W * CIN;
-  for (int c0 = 0; c0 < CIN; c0 += CB) {
-    __syncthreads();
-    // ---- stage input patch (4 threads x float4 per pixel)
-    for (int i = tid; i < G::PH * G::PW * (CB / 4); i += 256) {
-      const int c4 = i & 3, p = i >> 2;
-      const int py = p / G::PW, px = p % G::PW;
-      const int iy = y0 * S - 1 + py, ix = x0 * S - 1 + px;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = *reinterpret_cast<const float4*>(X + xb + ((long)iy * W + ix) * CIN + c0 + 4 * c4);
-      int off;
-      if (S == 1) off = (py * G::PW + px) * CLD + 4 * c4;
-      else off = ((py * 2 + (px & 1)) * G::PWH + (px >> 1)) * CLD + 4 * c4;
-      *reinterpret_cast<float4*>(patch + off) = v;
-    }
-    // ---- stage weights [9][BN][CB]
-    for (int i = tid; i < 9 * BN * (CB / 4); i += 256) {
+  // ---- software pipeline: the global loads of channel block c+1 are issued into registers before
+  // the MFMAs of block c and written to LDS after them, so HBM/L2 latency hides under the matrix
+  // pipe.  Source / destination offsets do not depend on the channel block: computed once.
+  constexpr int NPF4 = G::PH * G::PW * (CB / 4);  // float4 slots of the patch
+  constexpr int NP = (NPF4 + 255) / 256;
+  constexpr int NWF4 = 9 * BN * (CB / 4);         // float4 slots of the weight slab
+  constexpr int NW = (NWF4 + 255) / 256;
+  // buffer descriptors (wave-uniform: kernel arguments + blockIdx only): 32-bit byte offsets per lane,
+  // hardware bounds check -> the zero padding of the halo costs nothing (offset 2^31 is out of range)
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(X + (long)b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(Wg + (long)n0 * CIN), 0, (9 * COUT - n0) * CIN * 4, 0x00020000);
+  constexpr int OOB = (int)0x80000000;
+  int gp[NP];  // byte offset of this thread's e-th patch slot, OOB = zero padding / no slot
+#pragma unroll
+  for (int e = 0; e < NP; ++e) {
+    const int i = tid + 256 * e;
+    const int c4 = i & 3, pp = i >> 2;
+    const int py = pp / G::PW, px = pp % G::PW;
+    const int iy = y0 * S - 1 + py, ix = x0 * S - 1 + px;
+    gp[e] = (i < NPF4 && iy >= 0 && iy < H && ix >= 0 && ix < W) ? ((iy * W + ix) * CIN + 4 * c4) * 4 : OOB;
+  }
+  u32x4 rp[NP], rw[NW];
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < NP; ++e) rp[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, gp[e], c0 * 4, 0);
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int i = tid + 256 * e;
       const int c4 = i & 3, rn = i >> 2;  // rn = tap*BN + n
       const int tap = rn / BN, n = rn % BN;
-      const float4 v =
-          *reinterpret_cast<const float4*>(Wg + ((long)tap * COUT + n0 + n) * CIN + c0 + 4 * c4);
-      *reinterpret_cast<float4*>(wts + rn * CLD + 4 * c4) = v;
+      const int off = (NWF4 % 256 == 0 || i < NWF4) ? ((tap * COUT + n) * CIN + 4 * c4) * 4 : OOB;
+      rw[e] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, c0 * 4, 0);
     }
-    __syncthreads();
-    // ---- 9 taps x 8 k-steps
+  };
+  auto lstore = [&]() {
 #pragma unroll
+    for (int e = 0; e < NP; ++e) {
+      const int i = tid + 256 * e;
+      const int c4 = i & 3, pp = i >> 2;
+      const int py = pp / G::PW, px = pp % G::PW;
+      int off;
+      if (S == 1) off = pp * CLD + 4 * c4;
+      else off = ((py * 2 + (px & 1)) * G::PWH + (px >> 1)) * CLD + 4 * c4;
+      if (NPF4 % 256 == 0 || i < NPF4)
+        *reinterpret_cast<u32x4*>(patch + off) = rp[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NW; ++e) {
+      const int i = tid + 256 * e;
+      if (NWF4 % 256 == 0 || i < NWF4)
+        *reinterpret_cast<u32x4*>(wts + (i >> 2) * CLD + 4 * (i & 3)) = rw[e];
+    }
+  };
+
+  gload(0);
+  for (int c0 = 0; c0 < CIN; c0 += CB) {
+    __syncthreads();  // every wave is done reading the previous block from LDS
+    lstore();
+    __syncthreads();
+    if (c0 + CB < CIN) gload(c0 + CB);
+    // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure)
+#pragma unroll 1
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
@@ -173,26 +210,43 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float* __restrict__ X, in
             }
       }
   }
-  // ---- epilogue: lane holds channel n0 + 32j + li, pixels x = x0 + 32xt + (r&3) + 8(r>>2) + 4kh
+  // ---- epilogue: lane holds channel n0 + 32j + li, pixels x = x0 + 32xt + (r&3) + 8(r>>2) + 4kh.
+  // Branch-free buffer loads/stores (out-of-range pixels get an out-of-bounds offset: loads return 0,
+  // stores are dropped), so the 16 residual loads of a tile are in flight together instead of one
+  // HBM round trip per element.
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+      Y + (long)b * Ho * Wo * COUT, 0, Ho * Wo * COUT * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(R != nullptr ? R + (long)b * Ho * Wo * COUT : Y), 0, Ho * Wo * COUT * 4,
+      0x00020000);
 #pragma unroll
   for (int i = 0; i < MPW; ++i) {
     const int mt = wv * MPW + i;
     const int y = y0 + mt / TWT, xbase = x0 + 32 * (mt % TWT) + 4 * kh;
-    if (y >= Ho) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + 32 * j + li;
       const float sh = shift[n];
+      int off[16];
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int x = xbase + (r & 3) + 8 * (r >> 2);
-        if (x < Wo) {
-          const long o = (((long)b * Ho + y) * Wo + x) * COUT + n;
-          float v = acc[i][j][r] + sh;
-          if (R != nullptr) v += R[o];
-          if (relu) v = fmaxf(v, 0.f);
-          Y[o] = v;
-        }
+        off[r] = (y < Ho && x < Wo) ? ((y * Wo + x) * COUT + n) * 4 : OOB;
+      }
+      if (R != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrd, off[r], 0, 0));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + sh + rv[r];
+        if (relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ysrd, off[r], 0, 0);
       }
     }
   }
@@ -259,9 +313,9 @@ int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, co
   pa::ProfScope prof("k_conv3x3", stream, 2.0 * 9 * cin * cout * (double)B * Ho * Wo_,
                      4.0 * ((double)B * H * W * cin + (double)B * Ho * Wo_ * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   if (stride == 1) {
-    if (cout == 32) pa::launch_conv<1, 8, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    if (cout == 32) pa::launch_conv<1, 8, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else if (Ho >= 32) pa::launch_conv<1, 8, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
-    else if (Ho >= 16) pa::launch_conv<1, 4, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else if (Ho >= 16) pa::launch_conv<1, 4, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else pa::launch_conv<1, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
   } else if (stride == 2) {
     PA_REQUIRE(cout % 64 == 0, "pa_conv3x3: stride 2 needs cout %% 64 == 0");

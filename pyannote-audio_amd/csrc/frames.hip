@@ -1,0 +1,240 @@
+// Frame-domain stages of the diarization pipeline on gfx950: everything between the per-chunk hard
+// segmentations and the per-frame speaker decisions.  These are the reference's Python hot loops
+// #2, #4 and #5: ~213 k global frames per audio-hour walked in the interpreter.
+// All arithmetic here is on small integers (0/1 activities summed over <= ~10 overlapping chunks), so
+// the float32 sums of the reference are reproduced exactly with int32 atomics in any order; the one
+// float32 division of speaker counting is performed as the reference does (IEEE divide, rint-to-even).
+//
+//   k_chunk_stats      per (chunk, speaker): #active frames, #frames where it speaks alone
+//                      (clustering.py:109-116 filter, speaker_diarization.py:385-391 overlap exclusion,
+//                       :681-685 inactive speakers)
+//   k_embedding_masks  mask selection of get_embeddings (speaker_diarization.py:375-427) -> (C,S,F) fp32
+//   k_count_scatter / k_count_finish
+//                      speaker_count = aggregate(sum_s seg, hamming=False, missing=0) -> rint -> uint8
+//                      (pipelines/utils/diarization.py:150-185, core/inference.py:498-620)
+//   k_cluster_scatter  reconstruct (speaker_diarization.py:480-528: per chunk max over the local speakers
+//                      assigned to cluster k, NaN otherwise) + aggregate(skip_average=True) (overlap SUM)
+//   k_topk_binarize    to_diarization (diarization.py:250-266): per frame the count[t] most active
+//                      clusters.  The reference selects with np.argsort(-act), whose order among EQUAL
+//                      activations is unspecified (numpy's default sort is not stable: on AVX-512/AVX2
+//                      hosts it is a SIMD sorting network).  The kernel picks ties by lowest index and
+//                      FLAGS every frame where a tie straddles the selection boundary; the caller
+//                      re-decides exactly those frames with numpy's own argsort (frames.py), so the
+//                      result equals the reference's on whatever host it runs.
+//
+// HBM-bound streaming kernels; the inputs are 6.3 MB (uint8 segmentations) per audio-hour.
+#include "common.h"
+
+namespace pa {
+
+// grid = C, block = 256.  seg: (C, F, S) uint8, S <= 8.
+__global__ __launch_bounds__(256) void k_chunk_stats(const uint8_t* __restrict__ seg, int F, int S,
+                                                      int* __restrict__ active,
+                                                      int* __restrict__ clean) {
+  __shared__ int red[2][8][4];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint8_t* p = seg + (long)c * F * S;
+  int a[8], q[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) a[s] = q[s] = 0;
+  for (int f = tid; f < F; f += 256) {
+    int v[8], tot = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      v[s] = s < S ? p[f * S + s] : 0;
+      tot += v[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      a[s] += v[s];
+      q[s] += (tot == 1) ? v[s] : 0;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a[s] += __shfl_xor(a[s], o, 64);
+      q[s] += __shfl_xor(q[s], o, 64);
+    }
+    if (lane == 0) {
+      red[0][s][w] = a[s];
+      red[1][s][w] = q[s];
+    }
+  }
+  __syncthreads();
+  if (tid < S) {
+    active[c * S + tid] = red[0][tid][0] + red[0][tid][1] + red[0][tid][2] + red[0][tid][3];
+    clean[c * S + tid] = red[1][tid][0] + red[1][tid][1] + red[1][tid][2] + red[1][tid][3];
+  }
+}
+
+// masks[c][s][f] = use_clean(c,s) ? seg*[sum_s seg < 2] : seg ;  use_clean = exclude && clean > min_frames
+// grid = (ceil(F/256), C), block = 256
+__global__ __launch_bounds__(256) void k_embedding_masks(const uint8_t* __restrict__ seg, int F, int S,
+                                                          const int* __restrict__ clean,
+                                                          int exclude_overlap, int min_num_frames,
+                                                          float* __restrict__ masks) {
+  const int c = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const uint8_t* p = seg + ((long)c * F + f) * S;
+  int tot = 0;
+  for (int s = 0; s < S; ++s) tot += p[s];
+  for (int s = 0; s < S; ++s) {
+    const bool use_clean = exclude_overlap && clean[c * S + s] > min_num_frames;
+    const int v = p[s];
+    masks[((long)c * S + s) * F + f] = (float)((use_clean && tot >= 2) ? 0 : v);
+  }
+}
+
+// acc[2t] += sum_s seg[c][f][s], acc[2t+1] += 1  for t = start[c] + f.  grid = (ceil(F/256), C)
+__global__ __launch_bounds__(256) void k_count_scatter(const uint8_t* __restrict__ seg, int F, int S,
+                                                        const int* __restrict__ start, int T,
+                                                        int* __restrict__ acc) {
+  const int c = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const int t = start[c] + f;
+  if (t < 0 || t >= T) return;
+  const uint8_t* p = seg + ((long)c * F + f) * S;
+  int tot = 0;
+  for (int s = 0; s < S; ++s) tot += p[s];
+  if (tot) atomicAdd(acc + 2 * t, tot);
+  atomicAdd(acc + 2 * t + 1, 1);
+}
+
+__global__ __launch_bounds__(256) void k_count_finish(const int* __restrict__ acc, int T,
+                                                       uint8_t* __restrict__ count) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int n = acc[2 * t + 1];
+  // float32: aggregated / max(overlapping_chunk_count, 1e-12), missing -> 0, np.rint (half to even)
+  const float avg = n > 0 ? __fdiv_rn((float)acc[2 * t], (float)n) : 0.f;
+  count[t] = (uint8_t)rintf(avg);
+}
+
+// act[t][k] += max_{s : hard[c][s] == k} seg[c][f][s].  grid = (ceil(F/256), C)
+__global__ __launch_bounds__(256) void k_cluster_scatter(const uint8_t* __restrict__ seg, int F, int S,
+                                                          const int* __restrict__ start,
+                                                          const int* __restrict__ hard, int K, int T,
+                                                          int* __restrict__ act) {
+  const int c = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const int t = start[c] + f;
+  if (t < 0 || t >= T) return;
+  const uint8_t* p = seg + ((long)c * F + f) * S;
+  const int* h = hard + c * S;
+  for (int s = 0; s < S; ++s) {
+    const int k = h[s];
+    if (k < 0 || k >= K || !p[s]) continue;
+    // one contribution per (chunk, frame, cluster): only the first active local speaker of k adds
+    bool first = true;
+    for (int s2 = 0; s2 < s; ++s2) first = first && !(h[s2] == k && p[s2]);
+    if (first) atomicAdd(act + (long)t * K + k, 1);
+  }
+}
+
+// out[t][k] = 1 for the min(count[t], cap, K) largest act[t][.], ties -> lowest k.  One thread per frame.
+__global__ __launch_bounds__(256) void k_topk_binarize(const int* __restrict__ act,
+                                                        const uint8_t* __restrict__ count, int T, int K,
+                                                        int cap, uint8_t* __restrict__ out,
+                                                        uint8_t* __restrict__ tie) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int* a = act + (long)t * K;
+  uint8_t* o = out + (long)t * K;
+  for (int k = 0; k < K; ++k) o[k] = 0;
+  int n = count[t];
+  n = n < cap ? n : cap;
+  n = n < K ? n : K;
+  int last_v = 0x7fffffff, last_k = -1;  // previously selected (value, index): next pick is "after" it
+  for (int i = 0; i < n; ++i) {
+    int best_v = -1, best_k = -1;
+    for (int k = 0; k < K; ++k) {
+      const int v = a[k];
+      const bool after = v < last_v || (v == last_v && k > last_k);
+      if (after && v > best_v) {
+        best_v = v;
+        best_k = k;
+      }
+    }
+    if (best_k < 0) break;
+    o[best_k] = 1;
+    last_v = best_v;
+    last_k = best_k;
+  }
+  // ambiguous iff an unselected cluster has the same activation as the last selected one
+  bool amb = false;
+  if (n > 0 && n < K)
+    for (int k = 0; k < K; ++k) amb = amb || (!o[k] && a[k] == last_v);
+  tie[t] = amb ? 1 : 0;
+}
+
+}  // namespace pa
+
+extern "C" {
+
+int pa_seg_chunk_stats(const uint8_t* seg, int C, int F, int S, int32_t* active, int32_t* clean,
+                       void* stream) {
+  if (C <= 0) return 0;
+  PA_REQUIRE(S >= 1 && S <= 8, "pa_seg_chunk_stats: 1 <= S <= 8 required (got %d)", S);
+  pa::ProfScope prof("k_chunk_stats", stream, 2.0 * C * F * S, (double)C * F * S + 8.0 * C * S);
+  hipLaunchKernelGGL(pa::k_chunk_stats, dim3(C), dim3(256), 0, (hipStream_t)stream, seg, F, S, active,
+                     clean);
+  PA_CHECK_LAUNCH("pa_seg_chunk_stats");
+  return 0;
+}
+
+int pa_embedding_masks(const uint8_t* seg, int C, int F, int S, const int32_t* clean,
+                       int exclude_overlap, int min_num_frames, float* masks, void* stream) {
+  if (C <= 0) return 0;
+  pa::ProfScope prof("k_embedding_masks", stream, 1.0 * C * F * S, 5.0 * C * F * S);
+  hipLaunchKernelGGL(pa::k_embedding_masks, dim3(pa::cdiv(F, 256), C), dim3(256), 0,
+                     (hipStream_t)stream, seg, F, S, clean, exclude_overlap, min_num_frames, masks);
+  PA_CHECK_LAUNCH("pa_embedding_masks");
+  return 0;
+}
+
+int pa_speaker_count(const uint8_t* seg, int C, int F, int S, const int32_t* start_frame, int T,
+                     uint8_t* count, int32_t* scratch, void* stream) {
+  if (T <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  pa::ProfScope prof("k_speaker_count", stream, 1.0 * C * F * S, (double)C * F * S + 9.0 * T);
+  if (hipMemsetAsync(scratch, 0, sizeof(int32_t) * 2 * (size_t)T, st) != hipSuccess) {
+    pa::set_error("pa_speaker_count: memset failed");
+    return 1;
+  }
+  if (C > 0)
+    hipLaunchKernelGGL(pa::k_count_scatter, dim3(pa::cdiv(F, 256), C), dim3(256), 0, st, seg, F, S,
+                       start_frame, T, scratch);
+  hipLaunchKernelGGL(pa::k_count_finish, dim3(pa::cdiv(T, 256)), dim3(256), 0, st, scratch, T, count);
+  PA_CHECK_LAUNCH("pa_speaker_count");
+  return 0;
+}
+
+int pa_cluster_activations(const uint8_t* seg, int C, int F, int S, const int32_t* start_frame,
+                           const int32_t* hard, int K, int T, int32_t* act, void* stream) {
+  if (T <= 0 || K <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  pa::ProfScope prof("k_cluster_scatter", stream, 1.0 * C * F * S, (double)C * F * S + 4.0 * T * K);
+  if (hipMemsetAsync(act, 0, sizeof(int32_t) * (size_t)T * K, st) != hipSuccess) {
+    pa::set_error("pa_cluster_activations: memset failed");
+    return 1;
+  }
+  if (C > 0)
+    hipLaunchKernelGGL(pa::k_cluster_scatter, dim3(pa::cdiv(F, 256), C), dim3(256), 0, st, seg, F, S,
+                       start_frame, hard, K, T, act);
+  PA_CHECK_LAUNCH("pa_cluster_activations");
+  return 0;
+}
+
+int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
+                     uint8_t* tie, void* stream) {
+  if (T <= 0 || K <= 0) return 0;
+  pa::ProfScope prof("k_topk_binarize", stream, 1.0 * T * K, 5.0 * T * K + T);
+  hipLaunchKernelGGL(pa::k_topk_binarize, dim3(pa::cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, act,
+                     count, T, K, cap, out, tie);
+  PA_CHECK_LAUNCH("pa_topk_binarize");
+  return 0;
+}
+
+}  // extern "C"

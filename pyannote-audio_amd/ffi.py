@@ -113,6 +113,12 @@ _OPTIONAL: list[tuple] = [
     ("pa_gather_s2", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_pdist_f64", [c_fp, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_cdist_cosine_f64", [c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_seg_chunk_stats", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_embedding_masks", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
+    ("pa_speaker_count", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_cluster_activations", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp],
+     C.c_int),
+    ("pa_topk_binarize", [c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
     ("pa_stats_pool", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp,
                        c_fp], C.c_int),
 ]

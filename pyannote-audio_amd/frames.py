@@ -1,0 +1,121 @@
+"""Frame-domain stages on the GPU (csrc/frames.hip): speaker counting, overlap-add reconstruction,
+top-k discretisation, per-(chunk, speaker) statistics and embedding-mask selection.
+
+Mirrors pipelines/utils/diarization.py:150-268, pipelines/speaker_diarization.py:375-427, 480-528 and
+the overlap-add of core/inference.py:498-620 for the case the diarization pipeline uses (hamming=False,
+warm_up=(0, 0), hard {0,1} scores).  Results are bit-identical to the reference's float32 arithmetic
+(small-integer sums; see the kernel file).  There is no host implementation behind these calls."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import ffi
+from .core import SlidingWindow, SlidingWindowFeature
+
+
+def frame_geometry(chunks: SlidingWindow, frames: SlidingWindow, num_chunks: int
+                   ) -> Tuple[np.ndarray, int, SlidingWindow]:
+    """start frame of every chunk and the total number of global frames, in the reference's float64
+    arithmetic (core/inference.py:529-571, :596)."""
+    out_frames = SlidingWindow(start=chunks.start, duration=frames.duration, step=frames.step)
+    num_frames = out_frames.closest_frame(
+        chunks.start + chunks.duration + (num_chunks - 1) * chunks.step + 0.5 * out_frames.duration) + 1
+    c = np.arange(num_chunks, dtype=np.float64)
+    t = (chunks.start + c * chunks.step) + 0.5 * out_frames.duration
+    starts = np.rint((t - out_frames.start - 0.5 * out_frames.duration) / out_frames.step)
+    return starts.astype(np.int32), int(num_frames), out_frames
+
+
+def as_device_segmentation(seg, device: torch.device) -> torch.Tensor:
+    """(C, F, S) uint8 device tensor from a device tensor or a host array of {0,1} (NaN -> 0)."""
+    if isinstance(seg, torch.Tensor):
+        return seg.to(device=device, dtype=torch.uint8).contiguous()
+    return torch.from_numpy(np.nan_to_num(np.asarray(seg), nan=0.0).astype(np.uint8)).to(device)
+
+
+def chunk_stats(seg: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> active (C,S) int32 = #frames speaker s is on, clean (C,S) int32 = #frames it speaks alone."""
+    C, F, S = seg.shape
+    active = torch.empty((C, S), dtype=torch.int32, device=seg.device)
+    clean = torch.empty((C, S), dtype=torch.int32, device=seg.device)
+    ffi.check(ffi.load().pa_seg_chunk_stats(ffi.ptr(seg), C, F, S, ffi.ptr(active), ffi.ptr(clean),
+                                            ffi.stream()), "pa_seg_chunk_stats")
+    return active, clean
+
+
+def embedding_masks(seg: torch.Tensor, clean: torch.Tensor, exclude_overlap: bool,
+                    min_num_frames: int) -> torch.Tensor:
+    C, F, S = seg.shape
+    masks = torch.empty((C, S, F), dtype=torch.float32, device=seg.device)
+    ffi.check(ffi.load().pa_embedding_masks(ffi.ptr(seg), C, F, S, ffi.ptr(clean), int(exclude_overlap),
+                                            int(min_num_frames), ffi.ptr(masks), ffi.stream()),
+              "pa_embedding_masks")
+    return masks
+
+
+def speaker_count(seg: torch.Tensor, chunks: SlidingWindow, frames: SlidingWindow
+                  ) -> SlidingWindowFeature:
+    """pipelines/utils/diarization.py:150-185 with warm_up=(0, 0)."""
+    C, F, S = seg.shape
+    starts, T, out_frames = frame_geometry(chunks, frames, C)
+    dev = seg.device
+    st = torch.from_numpy(starts).to(dev)
+    count = torch.empty(T, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(2 * T, dtype=torch.int32, device=dev)
+    ffi.check(ffi.load().pa_speaker_count(ffi.ptr(seg), C, F, S, ffi.ptr(st), T, ffi.ptr(count),
+                                          ffi.ptr(scratch), ffi.stream()), "pa_speaker_count")
+    return SlidingWindowFeature(count.cpu().numpy().reshape(T, 1), out_frames)
+
+
+class Reconstructor:
+    """speaker_diarization.py:480-528 + diarization.py:221-268: cluster activations are accumulated
+    once, then discretised for any per-frame cap (regular and exclusive diarization share them)."""
+
+    def __init__(self, seg: torch.Tensor, chunks: SlidingWindow, frames: SlidingWindow,
+                 hard_clusters: np.ndarray, count: np.ndarray):
+        C, F, S = seg.shape
+        dev = seg.device
+        starts, T, self.frames = frame_geometry(chunks, frames, C)
+        count = np.ascontiguousarray(count.reshape(-1))
+        if len(count) != T:
+            raise ValueError(f"count has {len(count)} frames, the chunks cover {T}")
+        num_clusters = int(np.max(hard_clusters)) + 1
+        # to_diarization pads the cluster axis up to max(count) (diarization.py:250-256)
+        self.K = max(num_clusters, int(np.max(count)) if len(count) else 0, 1)
+        self.T = T
+        self.count = torch.from_numpy(count.astype(np.uint8)).to(dev)
+        hard = torch.from_numpy(np.ascontiguousarray(hard_clusters, dtype=np.int32)).to(dev)
+        st = torch.from_numpy(starts).to(dev)
+        self.act = torch.empty((T, self.K), dtype=torch.int32, device=dev)
+        ffi.check(ffi.load().pa_cluster_activations(ffi.ptr(seg), C, F, S, ffi.ptr(st), ffi.ptr(hard),
+                                                    self.K, T, ffi.ptr(self.act), ffi.stream()),
+                  "pa_cluster_activations")
+
+    def discretize(self, cap: int = 255) -> SlidingWindowFeature:
+        """Top-min(count[t], cap) clusters per frame.  Frames whose selection boundary falls inside a
+        group of EQUAL activations are re-decided with `np.argsort(-activations)` -- the reference's
+        own call (diarization.py:261), whose order among equals depends on the host's numpy build
+        (SIMD sorting networks) -- so the output equals the reference's on this host, not merely up
+        to ties.  Every other frame is decided on the GPU."""
+        dev = self.act.device
+        out = torch.empty((self.T, self.K), dtype=torch.uint8, device=dev)
+        tie = torch.empty(self.T, dtype=torch.uint8, device=dev)
+        ffi.check(ffi.load().pa_topk_binarize(ffi.ptr(self.act), ffi.ptr(self.count), self.T, self.K,
+                                              int(cap), ffi.ptr(out), ffi.ptr(tie), ffi.stream()),
+                  "pa_topk_binarize")
+        idx = torch.nonzero(tie).view(-1)
+        binary = out.cpu().numpy().astype(np.float32)
+        if idx.numel():
+            rows = idx.cpu().numpy()
+            act = self.act[idx].cpu().numpy().astype(np.float32)
+            n = np.minimum(np.minimum(self.count[idx].cpu().numpy().astype(np.int64), cap), self.K)
+            order = np.argsort(-act, axis=-1)
+            keep = np.arange(self.K)[None, :] < n[:, None]
+            fixed = np.zeros_like(act)
+            fixed[np.nonzero(keep)[0], order[keep]] = 1.0
+            binary[rows] = fixed
+        self.num_tie_frames = int(idx.numel())
+        return SlidingWindowFeature(binary, self.frames)

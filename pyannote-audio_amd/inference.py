@@ -59,6 +59,7 @@ class Inference(BaseInference):
         self.batch_size = batch_size
         # device-side copy of the last hard segmentation, for the embedding stage
         self.last_device_output: Optional[torch.Tensor] = None
+        self.last_host_output: Optional[np.ndarray] = None   # its host image (identity-checked)
 
     def to(self, device: torch.device) -> "Inference":
         if not isinstance(device, torch.device):
@@ -94,6 +95,7 @@ class Inference(BaseInference):
                                           want_logp=want_logp, want_multilabel=not want_logp)
         self.last_device_output = ml
         outputs = (logp if want_logp else ml.to(torch.float32)).cpu().numpy()
+        self.last_host_output = None if want_logp else outputs
         if hook is not None:
             hook(completed=total, total=total)
 

@@ -19,11 +19,12 @@ from typing import Any, Callable, Mapping, Optional
 import numpy as np
 import torch
 
+from . import frames as frame_ops
 from . import parallel
 from .agglomerative import Clustering
 from .audio import Audio, AudioFile
 from .core import Annotation, SlidingWindow, SlidingWindowFeature
-from .diarization import set_num_speakers, speaker_count, to_annotation, to_diarization
+from .diarization import set_num_speakers, to_annotation
 from .inference import Inference
 from .model import Model
 from .pipeline import ParamDict, Pipeline, Uniform
@@ -131,22 +132,25 @@ class SpeakerDiarization(Pipeline):
         return self._segmentation.slide(waveform, self._audio.sample_rate, hook=hook,
                                         chunk_range=chunk_range)
 
-    def embedding_masks(self, binary: torch.Tensor, exclude_overlap: bool, duration: float
-                        ) -> torch.Tensor:
-        """Mask selection of get_embeddings (:375-427) for all (chunk, speaker) pairs at once.
-        binary: (C, F, S) {0,1} device tensor -> (C, S, F) float32 masks."""
-        seg = torch.nan_to_num(binary.to(torch.float32), nan=0.0)
-        num_chunks, num_frames, _ = seg.shape
-        if exclude_overlap:
-            min_num_samples = self._embedding.min_num_samples
-            num_samples = duration * self._embedding.sample_rate
-            min_num_frames = math.ceil(num_frames * min_num_samples / num_samples)
-            clean = seg * (seg.sum(dim=2, keepdim=True) < 2).to(seg.dtype)
-            use_clean = clean.sum(dim=1, keepdim=True) > min_num_frames
-            used = torch.where(use_clean, clean, seg)
-        else:
-            used = seg
-        return used.permute(0, 2, 1).contiguous()
+    def _device_segmentation(self, binary_segmentations: SlidingWindowFeature) -> torch.Tensor:
+        """(C, F, S) uint8 device copy of the hard segmentations: the tensor the segmentation kernels
+        just produced when it is still the same data, an upload otherwise (sharded / user-supplied)."""
+        dev = self._segmentation.last_device_output
+        if dev is None or tuple(dev.shape) != tuple(binary_segmentations.data.shape) \
+                or self._segmentation.last_host_output is not binary_segmentations.data:
+            dev = frame_ops.as_device_segmentation(binary_segmentations.data, self._segmentation.device)
+        cache = getattr(self, "_stats_cache", None)
+        if cache is None or cache[0] is not dev:
+            self._stats_cache = (dev, None)
+        return dev
+
+    def _chunk_stats(self, dev_bin: torch.Tensor):
+        cache = getattr(self, "_stats_cache", None)
+        if cache is not None and cache[0] is dev_bin and cache[1] is not None:
+            return cache[1]
+        stats = frame_ops.chunk_stats(dev_bin)
+        self._stats_cache = (dev_bin, stats)
+        return stats
 
     def get_embeddings(self, file, binary_segmentations: SlidingWindowFeature,
                        exclude_overlap: bool = False, hook: Optional[Callable] = None,
@@ -161,10 +165,16 @@ class SpeakerDiarization(Pipeline):
         window = self._audio.get_num_samples(duration, sr)
         step = round(binary_segmentations.sliding_window.step * sr)
         begin = 0 if chunk_range is None else chunk_range[0]
-        dev_bin = self._segmentation.last_device_output
-        if dev_bin is None or tuple(dev_bin.shape) != binary_segmentations.data.shape:
-            dev_bin = torch.from_numpy(np.nan_to_num(binary_segmentations.data, nan=0.0)).to(device)
-        masks = self.embedding_masks(dev_bin, exclude_overlap, duration)
+        dev_bin = self._device_segmentation(binary_segmentations)
+        _, clean = self._chunk_stats(dev_bin)
+        if exclude_overlap:
+            # speaker_diarization.py:375-382
+            min_num_samples = self._embedding.min_num_samples
+            num_samples = duration * self._embedding.sample_rate
+            min_num_frames = math.ceil(num_frames * min_num_samples / num_samples)
+        else:
+            min_num_frames = -1
+        masks = frame_ops.embedding_masks(dev_bin, clean, exclude_overlap, min_num_frames)
         batch_count = math.ceil(num_chunks * num_speakers / self.embedding_batch_size)
         if hook is not None:
             hook("embeddings", None, total=batch_count, completed=0)
@@ -189,22 +199,13 @@ class SpeakerDiarization(Pipeline):
 
     def reconstruct(self, segmentations: SlidingWindowFeature, hard_clusters: np.ndarray,
                     count: SlidingWindowFeature) -> SlidingWindowFeature:
-        """speaker_diarization.py:480-528: per chunk, activation of cluster k = max over the local
-        speakers assigned to k (NaN where no local speaker maps to k)."""
-        num_chunks, num_frames, local_num_speakers = segmentations.data.shape
-        num_clusters = np.max(hard_clusters) + 1
-        clustered = np.full((num_chunks, num_frames, num_clusters), np.nan)
-        seg = segmentations.data
-        for s in range(local_num_speakers):
-            k = hard_clusters[:, s]
-            valid = np.nonzero(k >= 0)[0]
-            if len(valid) == 0:
-                continue
-            cur = clustered[valid, :, k[valid]]           # (n, F)
-            new = seg[valid, :, s]
-            clustered[valid, :, k[valid]] = np.where(np.isnan(cur), new, np.maximum(cur, new))
-        clustered = SlidingWindowFeature(clustered, segmentations.sliding_window)
-        return to_diarization(clustered, count)
+        """speaker_diarization.py:480-528 (per chunk, activation of cluster k = max over the local
+        speakers assigned to k) followed by to_diarization (diarization.py:221-268), on the GPU."""
+        rec = frame_ops.Reconstructor(self._device_segmentation(segmentations),
+                                      segmentations.sliding_window,
+                                      self._segmentation.model.receptive_field, hard_clusters,
+                                      count.data)
+        return rec.discretize()
 
     # -----------------------------------------------------------------------------------------
     def apply(self, file: AudioFile, num_speakers: Optional[int] = None,
@@ -251,8 +252,9 @@ class SpeakerDiarization(Pipeline):
             hook("segmentation", segmentations)
             num_chunks = total_chunks
 
-        count = speaker_count(binarized_segmentations, self._segmentation.model.receptive_field,
-                              warm_up=(0.0, 0.0))
+        dev_seg = self._device_segmentation(binarized_segmentations)
+        count = frame_ops.speaker_count(dev_seg, binarized_segmentations.sliding_window,
+                                        self._segmentation.model.receptive_field)
         hook("speaker_counting", count)
 
         if np.nanmax(count.data) == 0.0:
@@ -268,10 +270,11 @@ class SpeakerDiarization(Pipeline):
                                              waveform=waveform)
         hook("embeddings", embeddings)
 
+        active_frames, clean_frames = (t.cpu().numpy() for t in self._chunk_stats(dev_seg))
         hard_clusters, _, centroids = self.clustering(
             embeddings=embeddings, segmentations=binarized_segmentations, num_clusters=num_speakers,
             min_clusters=min_speakers, max_clusters=max_speakers, file=file,
-            frames=self._segmentation.model.receptive_field)
+            frames=self._segmentation.model.receptive_field, num_clean_frames=clean_frames)
         num_different_speakers = np.max(hard_clusters) + 1
         if num_different_speakers < min_speakers or num_different_speakers > max_speakers:
             warnings.warn(textwrap.dedent(f"""
@@ -282,17 +285,20 @@ class SpeakerDiarization(Pipeline):
                 """))
         count.data = np.minimum(count.data, max_speakers).astype(np.int8)
 
-        inactive_speakers = np.sum(binarized_segmentations.data, axis=1) == 0
+        inactive_speakers = active_frames == 0
         hard_clusters[inactive_speakers] = -2
 
-        discrete_diarization = self.reconstruct(segmentations, hard_clusters, count)
+        reconstructor = frame_ops.Reconstructor(dev_seg, segmentations.sliding_window,
+                                                self._segmentation.model.receptive_field,
+                                                hard_clusters, count.data)
+        discrete_diarization = reconstructor.discretize()
         hook("discrete_diarization", discrete_diarization)
         diarization = to_annotation(discrete_diarization, min_duration_on=0.0,
                                     min_duration_off=self.segmentation.min_duration_off)
         diarization.uri = file["uri"]
 
         count.data = np.minimum(count.data, 1).astype(np.int8)
-        exclusive_discrete_diarization = self.reconstruct(segmentations, hard_clusters, count)
+        exclusive_discrete_diarization = reconstructor.discretize(cap=1)
         exclusive_diarization = to_annotation(exclusive_discrete_diarization, min_duration_on=0.0,
                                               min_duration_off=self.segmentation.min_duration_off)
         exclusive_diarization.uri = file["uri"]

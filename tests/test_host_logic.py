@@ -60,8 +60,15 @@ def test_reconstruct_and_binarize_match_oracle(monkeypatch):
     hard[rng.uniform(size=hard.shape) < 0.15] = -2
     count = D.speaker_count(SlidingWindowFeature(seg, CHUNKS), FRAMES, warm_up=(0.0, 0.0))
     count.data = np.minimum(count.data, 3).astype(np.int8)
-    sd = pa.SpeakerDiarization.__new__(pa.SpeakerDiarization)
-    got = pa.SpeakerDiarization.reconstruct(sd, SlidingWindowFeature(seg, CHUNKS), hard.copy(), count)
+    # SpeakerDiarization.reconstruct itself runs on the GPU (tests/test_frames_gpu.py); here the host
+    # `to_diarization` (general SlidingWindowFeature API) is checked on the same clustered activations
+    K = hard.max() + 1
+    clustered = np.full((C, seg.shape[1], K), np.nan)
+    for c in range(C):
+        for k in np.unique(hard[c]):
+            if k >= 0:
+                clustered[c, :, k] = np.max(seg[c][:, hard[c] == k], axis=1)
+    got = D.to_diarization(SlidingWindowFeature(clustered, CHUNKS), count)
     want = O.reconstruct(seg, OCH, hard.copy(), count.data, OFR)
     assert np.array_equal(got.data, want)
     ann = D.to_annotation(got)

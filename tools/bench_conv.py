@@ -1,0 +1,35 @@
+"""Per-shape timing of pa_conv3x3 on the ResNet34 layer shapes (development aid; HIP events through
+the library profiler).  usage: python tools/bench_conv.py [B] [reps]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pyannote_audio_amd.ffi as ffi
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda:0")
+lib = ffi.load()
+T = 998
+shapes = [  # (H, W, cin, cout, stride, residual)
+    (80, T, 32, 32, 1, True), (80, T, 32, 64, 2, False), (40, 499, 64, 64, 1, True),
+    (40, 499, 64, 128, 2, False), (20, 250, 128, 128, 1, True), (20, 250, 128, 256, 2, False),
+    (10, 125, 256, 256, 1, True)]
+for (H, W, ci, co, s, res) in shapes:
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    X = torch.randn(B, H, W, ci, device=dev)
+    Wg = torch.randn(9, co, ci, device=dev) * 0.05
+    sh = torch.randn(co, device=dev)
+    R = torch.randn(B, Ho, Wo, co, device=dev) if res else None
+    Y = torch.empty(B, Ho, Wo, co, device=dev)
+    def run():
+        ffi.check(lib.pa_conv3x3(ffi.ptr(X), B, H, W, ci, ffi.ptr(Wg), ffi.ptr(sh), ffi.ptr(R), ffi.ptr(Y),
+                                 co, s, 1, ffi.stream()), "conv")
+    run(); torch.cuda.synchronize()
+    ffi.prof_enable(True)
+    for _ in range(reps): run()
+    torch.cuda.synchronize()
+    r = ffi.prof_report()["k_conv3x3"]
+    ffi.prof_enable(False)
+    ms = r["ms"] / r["launches"]
+    print(f"conv {H}x{W} {ci}->{co} s{s}: {ms:.3f} ms  {r['flops']/r['ms']/1e9:.1f} TFLOP/s "
+          f"({r['flops']/r['ms']/1e9/157.3*100:.1f}% of f32 MFMA peak)", flush=True)
