@@ -257,6 +257,8 @@ def main():
             "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
             "stages_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage_sum.items()},
             "speakers": len(out.speaker_diarization.labels()),
+            "clustering_s": {k: (round(v, 4) if isinstance(v, float) else v)
+                             for k, v in pipeline.clustering.timings.items()},
             "roofline": roof,
             "kernels": kernels,
         }

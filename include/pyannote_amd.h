@@ -174,6 +174,13 @@ int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream);
 int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D, double* out,
                         double* norms, void* stream);
 
+/* Centroid-linkage dendrogram, bit-identical to scipy.cluster.hierarchy.linkage(y, "centroid")
+ * (pipelines/clustering.py:374-382).  D: condensed distances (n*(n-1)/2 doubles, e.g. straight from
+ * pa_pdist_f64), OVERWRITTEN;  Z: (n-1, 4) doubles in SciPy's layout [id_a, id_b, height, size]. */
+size_t pa_linkage_workspace_bytes(int n);
+int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Frame-domain stages (uint8 hard segmentations in, per-frame decisions out).  Replace the Python
  * loops of Inference.aggregate (core/inference.py:589-611), speaker_count

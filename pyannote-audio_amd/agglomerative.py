@@ -10,6 +10,7 @@ large enough and a device is available; the serial dendrogram merge stays in Sci
 (which accepts the condensed matrix: `linkage(pdist(X)) == linkage(X, metric="euclidean")`)."""
 from __future__ import annotations
 
+import time
 from enum import Enum
 from typing import Optional
 
@@ -28,6 +29,7 @@ class BaseClustering(Pipeline):
         self.metric = metric
         self.constrained_assignment = constrained_assignment
         self.device = None
+        object.__setattr__(self, "timings", {})   # wall seconds of the last call, per sub-step
 
     def to(self, device):
         self.device = device
@@ -94,9 +96,12 @@ class BaseClustering(Pipeline):
                  num_clusters: Optional[int] = None, min_clusters: Optional[int] = None,
                  max_clusters: Optional[int] = None, **kwargs):
         """clustering.py:214-289"""
+        self.timings.clear()
+        t0 = time.perf_counter()
         train_embeddings, train_chunk_idx, train_speaker_idx = self.filter_embeddings(
             embeddings, segmentations=segmentations,
             num_clean_frames=kwargs.get("num_clean_frames", None))
+        self.timings["filter"] = time.perf_counter() - t0
         num_embeddings, _ = train_embeddings.shape
         num_clusters, min_clusters, max_clusters = self.set_num_clusters(
             num_embeddings, num_clusters=num_clusters, min_clusters=min_clusters,
@@ -107,10 +112,14 @@ class BaseClustering(Pipeline):
             soft = np.ones((num_chunks, num_speakers, 1))
             centroids = np.mean(train_embeddings, axis=0, keepdims=True)
             return hard, soft, centroids
+        t0 = time.perf_counter()
         train_clusters = self.cluster(train_embeddings, min_clusters=min_clusters,
                                       max_clusters=max_clusters, num_clusters=num_clusters)
-        return self.assign_embeddings(embeddings, train_chunk_idx, train_speaker_idx, train_clusters,
-                                      constrained=self.constrained_assignment)
+        t1 = time.perf_counter()
+        out = self.assign_embeddings(embeddings, train_chunk_idx, train_speaker_idx, train_clusters,
+                                     constrained=self.constrained_assignment)
+        self.timings.update(cluster=t1 - t0, assign=time.perf_counter() - t1)
+        return out
 
 
 class AgglomerativeClustering(BaseClustering):
@@ -130,8 +139,19 @@ class AgglomerativeClustering(BaseClustering):
         if self.metric == "cosine" and self.method in ["centroid", "median", "ward"]:
             with np.errstate(divide="ignore", invalid="ignore"):
                 embeddings /= np.linalg.norm(embeddings, axis=-1, keepdims=True)
+            t0 = time.perf_counter()
+            if (self.method == "centroid" and len(embeddings) >= 2 and self.device is not None
+                    and getattr(self.device, "type", None) == "cuda"):
+                Z = distance.linkage_centroid(embeddings, self.device)
+                self.timings.update(pdist=0.0, linkage=time.perf_counter() - t0,
+                                    num_embeddings=len(embeddings))
+                return Z
             condensed = distance.pdist_euclidean(embeddings, device=self.device)
-            return linkage(condensed, method=self.method)
+            t1 = time.perf_counter()
+            Z = linkage(condensed, method=self.method)
+            self.timings.update(pdist=t1 - t0, linkage=time.perf_counter() - t1,
+                                num_embeddings=len(embeddings))
+            return Z
         if self.metric == "euclidean":
             condensed = distance.pdist_euclidean(embeddings, device=self.device)
             return linkage(condensed, method=self.method)

@@ -103,3 +103,24 @@ def test_silence_returns_empty(pipeline_dir, gpu_device):
     out = pipeline({"waveform": wav, "sample_rate": 16000, "uri": "z"})
     assert isinstance(out, pa.DiarizeOutput)
     assert isinstance(out.speaker_diarization, pa.Annotation)
+
+
+@pytest.mark.parametrize("n,d,dup,seed", [(2, 8, 0, 0), (3, 8, 0, 1), (50, 16, 0, 2), (257, 256, 0, 3),
+                                          (200, 16, 60, 4), (1500, 256, 25, 5), (4000, 64, 0, 6)])
+def test_linkage_centroid_bit_exact_vs_scipy(gpu_device, n, d, dup, seed):
+    """pa_pdist_f64 + pa_linkage_centroid_f64 == scipy linkage(pdist(X), "centroid"), including exact
+    ties produced by duplicated rows (same merge order, same float64 heights)."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+    from pyannote_audio_amd import distance
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((5, d))
+    X = (centers[rng.integers(0, 5, n)] + 0.4 * rng.standard_normal((n, d))).astype(np.float32)
+    if dup:
+        X[rng.integers(0, n, dup)] = X[rng.integers(0, n, dup)]
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    want = linkage(pdist(X), method="centroid")
+    got = distance.linkage_centroid(X, gpu_device)
+    assert got.shape == want.shape and got.dtype == np.float64
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
