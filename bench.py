@@ -221,6 +221,13 @@ def main():
     prof = ffi.prof_report()
     ffi.prof_enable(False)
 
+    if rank == 0 and os.environ.get("PA_BENCH_DUMP_EMB"):
+        hooked = {}
+        pipeline(file, hook=lambda step, art, **kw: hooked.__setitem__(step, art) if kw.get("total") is None else None)
+        emb, seg = hooked["embeddings"], hooked["segmentation"]
+        tr, _, _ = pipeline.clustering.filter_embeddings(emb, seg)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.save(os.path.join(ROOT, "gpurun_out", "bench_train_emb.npy"), tr.astype(np.float32))
     if rank == 0:
         kernels = {}
         for name, r in prof.items():
@@ -257,6 +264,7 @@ def main():
             "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
             "stages_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage_sum.items()},
             "speakers": len(out.speaker_diarization.labels()),
+            "apply_marks_s": {k: round(v, 4) for k, v in getattr(pipeline, "timings", {}).items()},
             "clustering_s": {k: (round(v, 4) if isinstance(v, float) else v)
                              for k, v in pipeline.clustering.timings.items()},
             "roofline": roof,

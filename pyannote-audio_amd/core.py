@@ -196,11 +196,53 @@ if not HAVE_PYANNOTE_CORE:
             return SlidingWindowFeature(-self.data, self.sliding_window, labels=self.labels)
 
     class Annotation:
+        """Segment -> {track: label} container (pyannote.core.Annotation subset).
+
+        Native storage is COLUMNAR when the annotation comes out of the pipeline
+        (`Annotation.from_columns`: start / end / track / label arrays straight from the run
+        boundaries of the frame-level decisions); `Segment` objects and the per-segment dicts are only
+        built when a caller edits or iterates.  `labels()`, `rename_labels()`, `to_rttm()` and `len()`
+        work on the columns."""
+
         def __init__(self, uri: Optional[str] = None, modality: Optional[str] = None):
             self.uri = uri
             self.modality = modality
-            self._tracks: dict = {}   # Segment -> {track: label}
+            self._dict: dict = {}     # Segment -> {track: label}
+            self._cols = None         # (starts f64, ends f64, tracks list, labels list) not yet in _dict
             self._sorted: Optional[list] = None
+
+        @classmethod
+        def from_columns(cls, starts, ends, tracks, labels, uri=None, modality=None) -> "Annotation":
+            """rows (start[i], end[i], tracks[i], labels[i]); empty segments (duration <= precision)
+            are dropped exactly like `annotation[segment, track] = label` drops them."""
+            starts = np.asarray(starts, dtype=np.float64)
+            ends = np.asarray(ends, dtype=np.float64)
+            keep = (ends - starts) > SEGMENT_PRECISION
+            out = cls(uri=uri, modality=modality)
+            if not keep.all():
+                idx = np.nonzero(keep)[0]
+                starts, ends = starts[idx], ends[idx]
+                tracks = [tracks[i] for i in idx]
+                labels = [labels[i] for i in idx]
+            out._cols = (starts, ends, list(tracks), list(labels))
+            return out
+
+        @property
+        def _tracks(self) -> dict:
+            if self._cols is not None:
+                starts, ends, tracks, labels = self._cols
+                self._cols = None
+                d = self._dict
+                for a, b, t, l in zip(starts.tolist(), ends.tolist(), tracks, labels):
+                    d.setdefault(Segment(a, b), {})[t] = l
+                self._sorted = None
+            return self._dict
+
+        @_tracks.setter
+        def _tracks(self, value: dict):
+            self._cols = None
+            self._dict = value
+            self._sorted = None
 
         # -- construction
         def __setitem__(self, key, label):
@@ -233,9 +275,13 @@ if not HAVE_PYANNOTE_CORE:
             return self._sorted
 
         def __len__(self):
+            if self._cols is not None and not self._dict:
+                return len(set(zip(self._cols[0].tolist(), self._cols[1].tolist())))
             return len(self._tracks)
 
         def __bool__(self):
+            if self._cols is not None and len(self._cols[0]):
+                return True
             return len(self._tracks) > 0
 
         def itersegments(self):
@@ -251,6 +297,8 @@ if not HAVE_PYANNOTE_CORE:
                         yield segment, track
 
         def labels(self) -> list:
+            if self._cols is not None and not self._dict:
+                return sorted(set(self._cols[3]), key=str)
             return sorted({l for t in self._tracks.values() for l in t.values()}, key=str)
 
         def get_timeline(self):
@@ -263,6 +311,15 @@ if not HAVE_PYANNOTE_CORE:
             if mapping is None:
                 gen = string_generator() if generator == "string" else itertools.count()
                 mapping = {label: next(gen) for label in self.labels()}
+            if self._cols is not None and not self._dict:
+                starts, ends, tracks, labels = self._cols
+                new_labels = [mapping.get(l, l) for l in labels]
+                if copy:
+                    out = Annotation(uri=self.uri, modality=self.modality)
+                    out._cols = (starts, ends, tracks, new_labels)
+                    return out
+                self._cols = (starts, ends, tracks, new_labels)
+                return self
             out = Annotation(uri=self.uri, modality=self.modality) if copy else self
             items = [(s, t, l) for s, t, l in self.itertracks(yield_label=True)]
             if not copy:

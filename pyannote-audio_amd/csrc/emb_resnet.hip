@@ -83,12 +83,13 @@ struct ConvGeom {
   static constexpr int PATCH = S == 1 ? PH * PW * CLD : PH * 2 * PWH * CLD;
 };
 
-template <int S, int TH, int TWT, int BN>
+template <int S, int TH, int TWT, int BN, bool HAS_R>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X, int H, int W, int CIN,
-                                                 const float* __restrict__ Wg,
-                                                 const float* __restrict__ shift,
-                                                 const float* __restrict__ R, float* __restrict__ Y,
-                                                 int Ho, int Wo, int COUT, int relu, int tiles_w) {
+                                                    const float* __restrict__ Wg,
+                                                    const float* __restrict__ shift,
+                                                    const float* __restrict__ R, float* __restrict__ Y,
+                                                    int Ho, int Wo, int COUT, int relu, int tiles_w,
+                                                    int tiles_hw, int n_tiles, int total_tiles) {
   using G = ConvGeom<S, TH, TWT>;
   constexpr int MT = TH * TWT;   // 32-pixel M-tiles per workgroup
   constexpr int MPW = MT / 4;    // M-tiles per wave
@@ -98,48 +99,50 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
   float* patch = smem;
   float* wts = smem + G::PATCH;
 
-  const int b = blockIdx.z;
-  const int n0 = blockIdx.y * BN;
-  const int ty = blockIdx.x / tiles_w, tx = blockIdx.x % tiles_w;
-  const int y0 = ty * TH, x0 = tx * G::TW;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 31, kh = lane >> 5;
-
-  f32x16 acc[MPW][NT];
-#pragma unroll
-  for (int i = 0; i < MPW; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- software pipeline: the global loads of channel block c+1 are issued into registers before
-  // the MFMAs of block c and written to LDS after them, so HBM/L2 latency hides under the matrix
-  // pipe.  Source / destination offsets do not depend on the channel block: computed once.
   constexpr int NPF4 = G::PH * G::PW * (CB / 4);  // float4 slots of the patch
   constexpr int NP = (NPF4 + 255) / 256;
   constexpr int NWF4 = 9 * BN * (CB / 4);         // float4 slots of the weight slab
   constexpr int NW = (NWF4 + 255) / 256;
-  // buffer descriptors (wave-uniform: kernel arguments + blockIdx only): 32-bit byte offsets per lane,
-  // hardware bounds check -> the zero padding of the halo costs nothing (offset 2^31 is out of range)
-  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(X + (long)b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(Wg + (long)n0 * CIN), 0, (9 * COUT - n0) * CIN * 4, 0x00020000);
   constexpr int OOB = (int)0x80000000;
-  int gp[NP];  // byte offset of this thread's e-th patch slot, OOB = zero padding / no slot
-#pragma unroll
-  for (int e = 0; e < NP; ++e) {
-    const int i = tid + 256 * e;
-    const int c4 = i & 3, pp = i >> 2;
-    const int py = pp / G::PW, px = pp % G::PW;
-    const int iy = y0 * S - 1 + py, ix = x0 * S - 1 + px;
-    gp[e] = (i < NPF4 && iy >= 0 && iy < H && ix >= 0 && ix < W) ? ((iy * W + ix) * CIN + 4 * c4) * 4 : OOB;
-  }
+
+  // Persistent workgroup: tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...  (t -> image b, channel
+  // tile n0, pixel tile y0/x0).  The (tile, channel-block) iteration space is ONE software pipeline:
+  // the global loads of the next stage -- the next 16-channel block of this tile or the first block of
+  // the NEXT tile -- are issued into registers (buffer_load_dwordx4, wave-uniform descriptor, hardware
+  // bounds check = free zero padding of the halo) before the MFMAs of the current stage and land in
+  // LDS after them, so neither a tile's prologue nor its epilogue leaves the matrix pipe idle.
+  struct Tile {
+    int b, n0, y0, x0;
+  };
+  auto decode = [&](int t) {
+    Tile q;
+    const int pix = t % tiles_hw;
+    const int rest = t / tiles_hw;
+    q.n0 = (rest % n_tiles) * BN;
+    q.b = rest / n_tiles;
+    q.y0 = (pix / tiles_w) * TH;
+    q.x0 = (pix % tiles_w) * G::TW;
+    return q;
+  };
   u32x4 rp[NP], rw[NW];
-  auto gload = [&](int c0) {
+  auto gload = [&](const Tile& q, int c0) {
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wg + (long)q.n0 * CIN), 0, (9 * COUT - q.n0) * CIN * 4, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < NP; ++e) rp[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, gp[e], c0 * 4, 0);
+    for (int e = 0; e < NP; ++e) {
+      const int i = tid + 256 * e;
+      const int c4 = i & 3, pp = i >> 2;
+      const int py = pp / G::PW, px = pp % G::PW;
+      const int iy = q.y0 * S - 1 + py, ix = q.x0 * S - 1 + px;
+      const int off = ((NPF4 % 256 == 0 || i < NPF4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                          ? ((iy * W + ix) * CIN + 4 * c4) * 4
+                          : OOB;
+      rp[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, c0 * 4, 0);
+    }
 #pragma unroll
     for (int e = 0; e < NW; ++e) {
       const int i = tid + 256 * e;
@@ -158,8 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
       int off;
       if (S == 1) off = pp * CLD + 4 * c4;
       else off = ((py * 2 + (px & 1)) * G::PWH + (px >> 1)) * CLD + 4 * c4;
-      if (NPF4 % 256 == 0 || i < NPF4)
-        *reinterpret_cast<u32x4*>(patch + off) = rp[e];
+      if (NPF4 % 256 == 0 || i < NPF4) *reinterpret_cast<u32x4*>(patch + off) = rp[e];
     }
 #pragma unroll
     for (int e = 0; e < NW; ++e) {
@@ -169,86 +171,119 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
     }
   };
 
-  gload(0);
-  for (int c0 = 0; c0 < CIN; c0 += CB) {
-    __syncthreads();  // every wave is done reading the previous block from LDS
-    lstore();
-    __syncthreads();
-    if (c0 + CB < CIN) gload(c0 + CB);
-    // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure)
+  int t = blockIdx.x;
+  if (t >= total_tiles) return;
+  Tile cur = decode(t);
+  gload(cur, 0);
+  for (; t < total_tiles; t += gridDim.x) {
+    f32x16 acc[MPW][NT];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int tn = t + gridDim.x;
+    Tile nxt = cur;
+    if (tn < total_tiles) nxt = decode(tn);
+
+    for (int c0 = 0; c0 < CIN; c0 += CB) {
+      __syncthreads();  // every wave is done reading the previous stage from LDS
+      lstore();
+      __syncthreads();
+      if (c0 + CB < CIN) gload(cur, c0 + CB);
+      else if (tn < total_tiles) gload(nxt, 0);
+      // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure)
 #pragma unroll 1
-    for (int dy = 0; dy < 3; ++dy)
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        float4 af[MPW][2], bf[NT][2];
+        for (int dx = 0; dx < 3; ++dx) {
+          float4 af[MPW][2], bf[NT][2];
 #pragma unroll
-        for (int i = 0; i < MPW; ++i) {
-          const int mt = wv * MPW + i;
-          const int yy = mt / TWT, xt = mt % TWT;
-          int off;
-          if (S == 1) off = ((yy + dy) * G::PW + 32 * xt + li + dx) * CLD;
-          else off = (((yy * 2 + dy) * 2 + (dx & 1)) * G::PWH + 32 * xt + li + (dx >> 1)) * CLD;
-          af[i][0] = *reinterpret_cast<const float4*>(patch + off + kh * 8);
-          af[i][1] = *reinterpret_cast<const float4*>(patch + off + kh * 8 + 4);
+          for (int i = 0; i < MPW; ++i) {
+            const int mt = wv * MPW + i;
+            const int yy = mt / TWT, xt = mt % TWT;
+            int off;
+            if (S == 1) off = ((yy + dy) * G::PW + 32 * xt + li + dx) * CLD;
+            else off = (((yy * 2 + dy) * 2 + (dx & 1)) * G::PWH + 32 * xt + li + (dx >> 1)) * CLD;
+            af[i][0] = *reinterpret_cast<const float4*>(patch + off + kh * 8);
+            af[i][1] = *reinterpret_cast<const float4*>(patch + off + kh * 8 + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int off = ((dy * 3 + dx) * BN + 32 * j + li) * CLD + kh * 8;
+            bf[j][0] = *reinterpret_cast<const float4*>(wts + off);
+            bf[j][1] = *reinterpret_cast<const float4*>(wts + off + 4);
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MPW; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                acc[i][j] = MFMA32(af[i][h].x, bf[j][h].x, acc[i][j]);
+                acc[i][j] = MFMA32(af[i][h].y, bf[j][h].y, acc[i][j]);
+                acc[i][j] = MFMA32(af[i][h].z, bf[j][h].z, acc[i][j]);
+                acc[i][j] = MFMA32(af[i][h].w, bf[j][h].w, acc[i][j]);
+              }
         }
+    }
+    // ---- epilogue: lane holds channel n0 + 32j + li, pixels x = x0 + 32xt + (r&3) + 8(r>>2) + 4kh.
+    // Branch-free buffer loads/stores (out-of-range pixels get an out-of-bounds offset: loads return
+    // 0, stores are dropped), so the 16 residual loads of a tile are in flight together.
+    {
+      const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+          Y + (long)cur.b * Ho * Wo * COUT, 0, Ho * Wo * COUT * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(HAS_R ? R + (long)cur.b * Ho * Wo * COUT : Y), 0,
+          Ho * Wo * COUT * 4, 0x00020000);
+      // groups g = (M-tile i, N-tile j); the residual loads of group g+1 are issued before the stores
+      // of group g (vmcnt retires in order), so the epilogue is one stream instead of a load->store
+      // round trip per group
+      constexpr int NG = MPW * NT;
+      int off[2][16];
+      float rv[2][16];
+      auto goffs = [&](int g, int* o) {
+        const int i = g / NT, j = g % NT;
+        const int mt = wv * MPW + i;
+        const int y = cur.y0 + mt / TWT, xbase = cur.x0 + 32 * (mt % TWT) + 4 * kh;
+        const int n = cur.n0 + 32 * j + li;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int off = ((dy * 3 + dx) * BN + 32 * j + li) * CLD + kh * 8;
-          bf[j][0] = *reinterpret_cast<const float4*>(wts + off);
-          bf[j][1] = *reinterpret_cast<const float4*>(wts + off + 4);
+        for (int r = 0; r < 16; ++r) {
+          const int x = xbase + (r & 3) + 8 * (r >> 2);
+          o[r] = (y < Ho && x < Wo) ? ((y * Wo + x) * COUT + n) * 4 : OOB;
         }
+      };
+      auto gres = [&](const int* o, float* v) {
+        if (HAS_R) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+          for (int r = 0; r < 16; ++r)
+            v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrd, o[r], 0, 0));
+        } else {
 #pragma unroll
-          for (int i = 0; i < MPW; ++i)
+          for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        }
+      };
+      goffs(0, off[0]);
+      gres(off[0], rv[0]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              acc[i][j] = MFMA32(af[i][h].x, bf[j][h].x, acc[i][j]);
-              acc[i][j] = MFMA32(af[i][h].y, bf[j][h].y, acc[i][j]);
-              acc[i][j] = MFMA32(af[i][h].z, bf[j][h].z, acc[i][j]);
-              acc[i][j] = MFMA32(af[i][h].w, bf[j][h].w, acc[i][j]);
-            }
-      }
-  }
-  // ---- epilogue: lane holds channel n0 + 32j + li, pixels x = x0 + 32xt + (r&3) + 8(r>>2) + 4kh.
-  // Branch-free buffer loads/stores (out-of-range pixels get an out-of-bounds offset: loads return 0,
-  // stores are dropped), so the 16 residual loads of a tile are in flight together instead of one
-  // HBM round trip per element.
-  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
-      Y + (long)b * Ho * Wo * COUT, 0, Ho * Wo * COUT * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(R != nullptr ? R + (long)b * Ho * Wo * COUT : Y), 0, Ho * Wo * COUT * 4,
-      0x00020000);
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+          goffs(g + 1, off[(g + 1) & 1]);
+          gres(off[(g + 1) & 1], rv[(g + 1) & 1]);
+        }
+        const int i = g / NT, j = g % NT;
+        const float sh = shift[cur.n0 + 32 * j + li];
 #pragma unroll
-  for (int i = 0; i < MPW; ++i) {
-    const int mt = wv * MPW + i;
-    const int y = y0 + mt / TWT, xbase = x0 + 32 * (mt % TWT) + 4 * kh;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + 32 * j + li;
-      const float sh = shift[n];
-      int off[16];
-      float rv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int x = xbase + (r & 3) + 8 * (r >> 2);
-        off[r] = (y < Ho && x < Wo) ? ((y * Wo + x) * COUT + n) * 4 : OOB;
-      }
-      if (R != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrd, off[r], 0, 0));
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + sh + rv[r];
-        if (relu) v = fmaxf(v, 0.f);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ysrd, off[r], 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + sh + rv[g & 1][r];
+          if (relu) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ysrd,
+                                                off[g & 1][r], 0, 0);
+        }
       }
     }
+    cur = nxt;
   }
 }
 
@@ -268,23 +303,40 @@ __global__ __launch_bounds__(256) void k_gather_s2(const float* __restrict__ X, 
       reinterpret_cast<const float4*>(X)[(((b * H + 2 * y) * W) + 2 * x) * C4 + c4];
 }
 
-template <int S, int TH, int TWT, int BN>
-static int launch_conv(const float* X, int B, int H, int W, int CIN, const float* Wg,
-                       const float* shift, const float* R, float* Y, int COUT, int relu,
-                       hipStream_t st) {
+template <int S, int TH, int TWT, int BN, bool HAS_R>
+static int launch_conv_r(const float* X, int B, int H, int W, int CIN, const float* Wg,
+                         const float* shift, const float* R, float* Y, int COUT, int relu,
+                         hipStream_t st) {
   using G = ConvGeom<S, TH, TWT>;
   const int Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tiles_w = cdiv(Wo, G::TW), tiles_h = cdiv(Ho, TH);
   const size_t lds = (size_t)(G::PATCH + 9 * BN * CLD) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_conv3x3<S, TH, TWT, BN>,
+  static int resident = 0;  // workgroups the chip holds at once (2 per CU: LDS- and VGPR-bound)
+  if (!resident) {
+    (void)hipFuncSetAttribute((const void*)k_conv3x3<S, TH, TWT, BN, HAS_R>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
+    int dev = 0, cus = 256, per_cu = 2;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3<S, TH, TWT, BN, HAS_R>, 256, lds) !=
+            hipSuccess || per_cu < 1)
+      per_cu = 2;
+    resident = cus * per_cu;
   }
-  hipLaunchKernelGGL((k_conv3x3<S, TH, TWT, BN>), dim3(tiles_w * tiles_h, COUT / BN, B), dim3(256),
-                     lds, st, X, H, W, CIN, Wg, shift, R, Y, Ho, Wo, COUT, relu, tiles_w);
+  const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / BN;
+  const long total = (long)tiles_hw * n_tiles * B;
+  const int grid = (int)(total < resident ? total : resident);
+  hipLaunchKernelGGL((k_conv3x3<S, TH, TWT, BN, HAS_R>), dim3(grid), dim3(256), lds, st, X, H, W, CIN, Wg,
+                     shift, R, Y, Ho, Wo, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total);
   return 0;
+}
+
+template <int S, int TH, int TWT, int BN>
+static int launch_conv(const float* X, int B, int H, int W, int CIN, const float* Wg,
+                       const float* shift, const float* R, float* Y, int COUT, int relu,
+                       hipStream_t st) {
+  return R != nullptr ? launch_conv_r<S, TH, TWT, BN, true>(X, B, H, W, CIN, Wg, shift, R, Y, COUT, relu, st)
+                      : launch_conv_r<S, TH, TWT, BN, false>(X, B, H, W, CIN, Wg, shift, R, Y, COUT, relu, st);
 }
 
 }  // namespace pa
@@ -312,8 +364,10 @@ int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, co
   // algorithmic work: 2*9*cin*cout per output pixel; bytes: input + output (+ residual) + weights once
   pa::ProfScope prof("k_conv3x3", stream, 2.0 * 9 * cin * cout * (double)B * Ho * Wo_,
                      4.0 * ((double)B * H * W * cin + (double)B * Ho * Wo_ * cout * (R ? 2 : 1) + 9.0 * cin * cout));
+  static const int l1_wide = getenv("PA_CONV_L1_WIDE") ? atoi(getenv("PA_CONV_L1_WIDE")) : 0;  // tuning aid
   if (stride == 1) {
-    if (cout == 32) pa::launch_conv<1, 8, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    if (cout == 32 && l1_wide) pa::launch_conv<1, 8, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else if (cout == 32) pa::launch_conv<1, 8, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else if (Ho >= 32) pa::launch_conv<1, 8, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else if (Ho >= 16) pa::launch_conv<1, 4, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else pa::launch_conv<1, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);

@@ -32,54 +32,65 @@ __device__ __forceinline__ long cidx(long n, long i, long j) {
   return i < j ? n * i - (i * (i + 1) / 2) + (j - i - 1) : n * j - (j * (j + 1) / 2) + (i - j - 1);
 }
 
+// SciPy's Heap (scipy/cluster/_structures.pxi) with "hole" sifts: the moving element is held in
+// registers and written once at its final position.  The final arrays are identical to the
+// swap-by-swap version (same comparisons, same order), at ~1/3 of the dependent LDS traffic.
 template <typename IT>
 struct Heap {
   double* v;  // values by heap position
   IT* kbi;    // key_by_index
   IT* ibk;    // index_by_key
   int size;
-  __device__ __forceinline__ void swap(int i, int j) {
-    const double t = v[i];
-    v[i] = v[j];
-    v[j] = t;
-    const IT ki = kbi[i], kj = kbi[j];
-    kbi[i] = kj;
-    kbi[j] = ki;
-    ibk[ki] = (IT)j;
-    ibk[kj] = (IT)i;
+  __device__ __forceinline__ void place(int index, double val, IT key) {
+    v[index] = val;
+    kbi[index] = key;
+    ibk[key] = (IT)index;
   }
-  __device__ void sift_up(int index) {
-    int parent = (index - 1) >> 1;
-    while (index > 0 && v[parent] > v[index]) {
-      swap(index, parent);
+  __device__ void sift_up(int index, double val, IT key) {
+    while (index > 0) {
+      const int parent = (index - 1) >> 1;
+      const double pv = v[parent];
+      const IT pk = kbi[parent];
+      if (!(pv > val)) break;
+      place(index, pv, pk);
       index = parent;
-      parent = (index - 1) >> 1;
     }
+    place(index, val, key);
   }
-  __device__ void sift_down(int index) {
+  __device__ void sift_down(int index, double val, IT key) {
     int child = 2 * index + 1;
     while (child < size) {
-      if (child + 1 < size && v[child + 1] < v[child]) child += 1;
-      if (v[index] > v[child]) {
-        swap(index, child);
-        index = child;
-        child = 2 * index + 1;
-      } else {
-        break;
+      double cv = v[child];
+      if (child + 1 < size) {
+        const double cv1 = v[child + 1];
+        if (cv1 < cv) {
+          child += 1;
+          cv = cv1;
+        }
       }
+      if (!(val > cv)) break;
+      place(index, cv, kbi[child]);
+      index = child;
+      child = 2 * index + 1;
     }
+    place(index, val, key);
+  }
+  __device__ void build() {  // Heap.__init__: sift_down from the last parent to the root
+    for (int i = size / 2 - 1; i >= 0; --i) sift_down(i, v[i], kbi[i]);
   }
   __device__ void change_value(int key, double value) {
     const int index = ibk[key];
     const double old = v[index];
-    v[index] = value;
-    if (value < old) sift_up(index);
-    else sift_down(index);
+    if (value < old) sift_up(index, value, (IT)key);
+    else sift_down(index, value, (IT)key);
   }
   __device__ void remove_min() {
-    swap(0, size - 1);
+    const int last = size - 1;
+    const double lv = v[last];
+    const IT lk = kbi[last];
+    place(last, v[0], kbi[0]);  // swap(0, size - 1): the removed root parks behind the heap
     size -= 1;
-    sift_down(0);
+    if (size > 0) sift_down(0, lv, lk);
   }
 };
 
@@ -99,13 +110,22 @@ __device__ MinPair block_find_min(const double* __restrict__ D, const int* __res
                                   int x, MinPair* red) {
   MinPair best{__builtin_inf(), -1};
   const long base = (long)n * x - ((long)x * (x + 1) / 2) - x - 1;  // cidx(n, x, i) = base + i
-  for (int i = x + 1 + threadIdx.x; i < n; i += LK_T) {
-    if (size[i] == 0) continue;
-    const double d = D[base + i];
-    if (d < best.d) {  // strict: the first (lowest i) minimum of this thread's ascending scan
-      best.d = d;
-      best.i = i;
+  for (int i0 = x + 1 + threadIdx.x; i0 < n; i0 += 4 * LK_T) {
+    // 4 row elements per thread in flight (ascending i, so the strict `<` keeps the first minimum)
+    double d[4];
+    bool act[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * LK_T;
+      act[u] = i < n && size[i] != 0;
+      d[u] = act[u] ? D[base + i] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (act[u] && d[u] < best.d) {
+        best.d = d[u];
+        best.i = i0 + u * LK_T;
+      }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -125,34 +145,44 @@ __device__ MinPair block_find_min(const double* __restrict__ D, const int* __res
   return r;
 }
 
+constexpr int LK_PEND = 256;  // lower-bound drops buffered per merge (more -> re-read from D)
+
 template <typename IT, bool LDS_HEAP>
 __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ D, int n,
                                                             double* __restrict__ Z,
                                                             int* __restrict__ size,
                                                             int* __restrict__ cluster_id,
-                                                            int* __restrict__ neighbor,
-                                                            double* __restrict__ min_dist,
                                                             double* __restrict__ g_hv,
                                                             int* __restrict__ g_kbi,
-                                                            int* __restrict__ g_ibk) {
+                                                            int* __restrict__ g_ibk,
+                                                            int* __restrict__ g_nb,
+                                                            long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ MinPair red[LK_W];
-  __shared__ int sh_x, sh_y, sh_ok, sh_nx, sh_ny;
+  __shared__ int sh_x, sh_y, sh_ok, sh_nx, sh_ny, sh_npend;
   __shared__ double sh_dist;
+  __shared__ int pend_z[LK_PEND], sort_z[LK_PEND];
+  __shared__ double pend_d[LK_PEND], sort_d[LK_PEND];
   const int tid = threadIdx.x;
-  const int hn = n - 1;  // heap capacity
+  const int hn = n - 1;  // heap capacity = rows that own a nearest-neighbour candidate
+  constexpr IT NONE = (IT)~(IT)0;  // "no neighbour" (-1)
 
+  // per-row state: heap (values = SciPy's min_dist, kept in sync with it), neighbour candidates
   Heap<IT> heap;
+  IT* nb;
   unsigned int* cand;  // bitmap of rows whose lower bound dropped in this merge
   if (LDS_HEAP) {
     heap.v = reinterpret_cast<double*>(lds_raw);
     heap.kbi = reinterpret_cast<IT*>(heap.v + hn);
     heap.ibk = heap.kbi + hn;
-    cand = reinterpret_cast<unsigned int*>(lds_raw + (((size_t)hn * (8 + 2 * sizeof(IT)) + 15) & ~(size_t)15));
+    nb = heap.ibk + hn;
+    cand = reinterpret_cast<unsigned int*>(
+        lds_raw + (((size_t)hn * (8 + 3 * sizeof(IT)) + 15) & ~(size_t)15));
   } else {
     heap.v = g_hv;
     heap.kbi = reinterpret_cast<IT*>(g_kbi);
     heap.ibk = reinterpret_cast<IT*>(g_ibk);
+    nb = reinterpret_cast<IT*>(g_nb);
     cand = reinterpret_cast<unsigned int*>(lds_raw);
   }
   heap.size = hn;
@@ -163,8 +193,7 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
     cluster_id[i] = i;
   }
   for (int i = tid; i < cand_words; i += LK_T) cand[i] = 0u;
-  __syncthreads();
-  // initial nearest-neighbour candidates (one wave per row)
+  // initial nearest-neighbour candidates (one wave per row); heap position i holds key i for now
   {
     const int lane = tid & 63, w = tid >> 6;
     for (int x = w; x < n - 1; x += LK_W) {
@@ -185,52 +214,59 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
         best = min_pair(best, other);
       }
       if (lane == 0) {
-        neighbor[x] = best.i;
-        min_dist[x] = best.i < 0 ? __builtin_inf() : best.d;
+        nb[x] = best.i < 0 ? NONE : (IT)best.i;
+        heap.v[x] = best.i < 0 ? __builtin_inf() : best.d;
+        heap.kbi[x] = (IT)x;
+        heap.ibk[x] = (IT)x;
       }
     }
   }
   __syncthreads();
-  for (int i = tid; i < hn; i += LK_T) {
-    heap.v[i] = min_dist[i];
-    heap.kbi[i] = (IT)i;
-    heap.ibk[i] = (IT)i;
+  if (tid == 0) {
+    heap.build();
+    sh_npend = 0;
   }
   __syncthreads();
-  if (tid == 0)
-    for (int i = hn / 2 - 1; i >= 0; --i) heap.sift_down(i);
-  __syncthreads();
 
+  // development counters (lane 0): [0] lower-bound repairs, [1] heap updates of the refresh,
+  // [2] refreshes that overflowed the pending buffer, [3..6] cycles in find / record / pass / replay
+  long long st_retry = 0, st_cand = 0, st_ovf = 0, st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0;
   for (int k = 0; k < n - 1; ++k) {
     // ---- find the two closest clusters: at most n - k lower-bound repairs
     int x = 0, y = 0;
     double dist = 0.0;
+    long long tc = __builtin_readcyclecounter();
     for (int it = 0; it < n - k; ++it) {
       if (tid == 0) {
         const int hx = heap.kbi[0];
         const double hd = heap.v[0];
-        const int hy = neighbor[hx];
+        const IT hyr = nb[hx];
+        const int hy = hyr == NONE ? -1 : (int)hyr;
         sh_x = hx;
         sh_y = hy;
         sh_dist = hd;
-        sh_ok = (hd == D[cidx(n, hx, hy)]) ? 1 : 0;
+        sh_ok = (hy >= 0 && hd == D[cidx(n, hx, hy)]) ? 1 : 0;
       }
       __syncthreads();
       x = sh_x;
       y = sh_y;
       dist = sh_dist;
       const int ok = sh_ok;
-      __syncthreads();
       if (ok) break;
-      const MinPair p = block_find_min(D, size, n, x, red);
+      const MinPair p = block_find_min(D, size, n, x, red);  // (barriers inside)
       y = p.i;
       dist = p.d;
       if (tid == 0) {
-        neighbor[x] = y;
-        min_dist[x] = dist;
+        nb[x] = y < 0 ? NONE : (IT)y;
         heap.change_value(x, dist);
+        ++st_retry;
       }
       __syncthreads();
+    }
+    {
+      const long long t2 = __builtin_readcyclecounter();
+      st_c0 += t2 - tc;
+      tc = t2;
     }
     // ---- record the merge
     if (tid == 0) {
@@ -253,61 +289,126 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
       sh_ny = ny;
     }
     __syncthreads();
-    const int nx = sh_nx, ny = sh_ny;
-    // ---- Lance-Williams (centroid) update of row/column y, all z in parallel
-    for (int z = tid; z < n; z += LK_T) {
-      const int nz = size[z];
-      if (nz == 0 || z == y) continue;
-      const long izy = cidx(n, z, y);
-      const double d_xi = D[cidx(n, z, x)], d_yi = D[izy];
-      D[izy] = sqrt((((nx * d_xi * d_xi) + (ny * d_yi * d_yi)) - ((nx * ny) * dist * dist) / (nx + ny)) /
-                    (nx + ny));
+    {
+      const long long t2 = __builtin_readcyclecounter();
+      st_c1 += t2 - tc;
+      tc = t2;
     }
-    __syncthreads();
-    // ---- neighbour reassignment (z < x) and lower-bound refresh (z < y): per-z independent parts in
-    // parallel, the heap updates afterwards by lane 0 in ascending z (SciPy's order)
-    for (int z = tid; z < n - 1; z += LK_T) {
-      if (size[z] == 0) continue;
-      if (z < x && neighbor[z] == x) neighbor[z] = y;
-      if (z < y) {
-        const double d = D[cidx(n, z, y)];
-        if (d < min_dist[z]) {
-          neighbor[z] = y;
-          min_dist[z] = d;
-          atomicOr(&cand[z >> 5], 1u << (z & 31));
+    const int nx = sh_nx, ny = sh_ny;
+    // ---- ONE pass over all clusters z (SciPy's four loops are independent per z except for the heap,
+    // which is replayed afterwards): Lance-Williams (centroid) update of D[z,y]; neighbour
+    // reassignment x -> y for z < x; lower-bound refresh for z < y; nearest neighbour of y among z > y.
+    MinPair best{__builtin_inf(), -1};
+    for (int z0 = tid; z0 < n; z0 += 4 * LK_T) {
+      // 4 clusters per thread: all 8 distance loads are issued before the first use
+      bool act[4];
+      long izy[4];
+      double d_xi[4], d_yi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int z = z0 + u * LK_T;
+        act[u] = z < n && z != y && size[z] != 0;
+        izy[u] = act[u] ? cidx(n, z, y) : 0;
+        d_xi[u] = act[u] ? D[cidx(n, z, x)] : 0.0;
+        d_yi[u] = act[u] ? D[izy[u]] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!act[u]) continue;
+        const int z = z0 + u * LK_T;
+        const double nd = sqrt(
+            (((nx * d_xi[u] * d_xi[u]) + (ny * d_yi[u] * d_yi[u])) - ((nx * ny) * dist * dist) / (nx + ny)) /
+            (nx + ny));
+        D[izy[u]] = nd;
+        if (z < y) {
+          if (z < x && nb[z] == (IT)x) nb[z] = (IT)y;
+          if (nd < heap.v[heap.ibk[z]]) {  // heap value of key z == SciPy's min_dist[z]
+            nb[z] = (IT)y;
+            atomicOr(&cand[z >> 5], 1u << (z & 31));
+            const int slot = atomicAdd(&sh_npend, 1);
+            if (slot < LK_PEND) {
+              pend_z[slot] = z;
+              pend_d[slot] = nd;
+            }
+          }
+        } else if (nd < best.d) {  // z > y, ascending per thread: first minimum
+          best.d = nd;
+          best.i = z;
         }
       }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      MinPair other;
+      other.d = __shfl_xor(best.d, o, 64);
+      other.i = __shfl_xor(best.i, o, 64);
+      best = min_pair(best, other);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    {
+      const long long t2 = __builtin_readcyclecounter();
+      st_c2 += t2 - tc;
+      tc = t2;
+    }
+    // ---- replay the heap updates in SciPy's order: ascending z < y, then row y.  The (few) refreshed
+    // rows are rank-sorted by z in parallel; lane 0 then only sifts.
+    const int np = sh_npend;  // (reset by lane 0 only after the next barrier)
+    if (np <= LK_PEND && tid < np) {
+      const int z = pend_z[tid];
+      int rank = 0;
+      for (int q = 0; q < np; ++q) rank += pend_z[q] < z ? 1 : 0;
+      sort_z[rank] = z;
+      sort_d[rank] = pend_d[tid];
+      cand[z >> 5] = 0u;  // (racing writers all store 0)
     }
     __syncthreads();
     if (tid == 0) {
-      const int words = (y + 31) / 32;
-      for (int wi = 0; wi < words; ++wi) {
-        unsigned int m = cand[wi];
-        if (!m) continue;
-        cand[wi] = 0u;
-        while (m) {
-          const int bit = __builtin_ctz(m);
-          m &= m - 1;
-          const int z = wi * 32 + bit;
-          heap.change_value(z, min_dist[z]);
+      sh_npend = 0;
+      st_cand += np;
+      if (np <= LK_PEND) {
+        for (int q = 0; q < np; ++q) heap.change_value(sort_z[q], sort_d[q]);
+      } else {
+        ++st_ovf;
+        const int words = (y + 31) / 32;
+        for (int wi = 0; wi < words; ++wi) {
+          unsigned int m = cand[wi];
+          if (!m) continue;
+          cand[wi] = 0u;
+          while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1;
+            const int z = wi * 32 + bit;
+            heap.change_value(z, D[cidx(n, z, y)]);
+          }
+        }
+      }
+      if (y < n - 1) {
+        MinPair r = red[0];
+#pragma unroll
+        for (int q = 1; q < LK_W; ++q) r = min_pair(r, red[q]);
+        if (r.i != -1) {
+          nb[y] = (IT)r.i;
+          heap.change_value(y, r.d);
         }
       }
     }
     __syncthreads();
-    // ---- nearest neighbour of the merged cluster
-    if (y < n - 1) {
-      const MinPair p = block_find_min(D, size, n, y, red);
-      if (tid == 0 && p.i != -1) {
-        neighbor[y] = p.i;
-        min_dist[y] = p.d;
-        heap.change_value(y, p.d);
-      }
-    }
-    __syncthreads();
+    st_c3 += __builtin_readcyclecounter() - tc;
+  }
+  if (tid == 0 && stats != nullptr) {
+    stats[0] = st_retry;
+    stats[1] = st_cand;
+    stats[2] = st_ovf;
+    stats[3] = st_c0;
+    stats[4] = st_c1;
+    stats[5] = st_c2;
+    stats[6] = st_c3;
+    stats[7] = n;
   }
 }
 
-constexpr size_t LK_LDS_MAX = 160 * 1024 - 2048;  // dynamic LDS budget (static part is < 1 KB)
+constexpr size_t LK_LDS_MAX = 160 * 1024 - 7680;  // dynamic LDS budget (static part: ~6.5 KB)
 
 inline size_t lk_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -318,7 +419,7 @@ extern "C" {
 size_t pa_linkage_workspace_bytes(int n) {
   if (n < 2) return 0;
   const size_t ni = pa::lk_align(sizeof(int) * (size_t)n), nd = pa::lk_align(sizeof(double) * (size_t)n);
-  return 5 * ni + 2 * nd;  // size, cluster_id, neighbor, kbi, ibk (int) + min_dist, heap values (double)
+  return 5 * ni + nd + 64;  // size, cluster_id, neighbour, kbi, ibk (int) + heap values (double) + 8 counters
 }
 
 // D: condensed distance matrix (n*(n-1)/2 doubles), OVERWRITTEN.  Z: (n-1, 4) doubles, SciPy layout.
@@ -333,11 +434,11 @@ int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t
   int* nb = (int*)(w + 2 * ni);
   int* kbi = (int*)(w + 3 * ni);
   int* ibk = (int*)(w + 4 * ni);
-  double* md = (double*)(w + 5 * ni);
-  double* hv = (double*)(w + 5 * ni + nd);
+  double* hv = (double*)(w + 5 * ni);
+  long long* stats = (long long*)(w + 5 * ni + nd);
   hipStream_t st = (hipStream_t)stream;
   const size_t cand_bytes = 4 * (size_t)((n + 31) / 32) + 16;
-  const size_t lds16 = (((size_t)(n - 1) * 12 + 15) & ~(size_t)15) + cand_bytes;
+  const size_t lds16 = (((size_t)(n - 1) * 14 + 15) & ~(size_t)15) + cand_bytes;
   // the merge loop is O(N^2) memory traffic in total; algorithmic bytes ~ 3 rows of 8*N per merge
   pa::ProfScope prof("k_linkage_centroid", stream, 9.0 * n * (double)n, 24.0 * n * (double)n);
   if (n <= 65535 && lds16 <= pa::LK_LDS_MAX) {
@@ -348,10 +449,10 @@ int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t
       attr = true;
     }
     hipLaunchKernelGGL((pa::k_linkage_centroid<unsigned short, true>), dim3(1), dim3(pa::LK_T), lds16, st,
-                       D, n, Z, size, cid, nb, md, hv, kbi, ibk);
+                       D, n, Z, size, cid, hv, kbi, ibk, nb, stats);
   } else {
     hipLaunchKernelGGL((pa::k_linkage_centroid<int, false>), dim3(1), dim3(pa::LK_T), cand_bytes, st, D, n,
-                       Z, size, cid, nb, md, hv, kbi, ibk);
+                       Z, size, cid, hv, kbi, ibk, nb, stats);
   }
   PA_CHECK_LAUNCH("pa_linkage_centroid_f64");
   return 0;

@@ -80,9 +80,9 @@ class Binarize:
         i = np.arange(num_frames, dtype=np.float64)
         start = frames.start + i * frames.step
         timestamps = 0.5 * (start + (start + frames.duration))   # Segment.middle of frames[i]
-        active = Annotation()
         track_generator = string_generator()
         labels = getattr(scores, "labels", None)
+        col_start, col_end, col_track, col_label = [], [], [], []
         for k in range(num_classes):
             y = scores.data[:, k]
             label = k if labels is None else labels[k]
@@ -99,15 +99,22 @@ class Binarize:
             np.maximum.accumulate(idx, out=idx)
             state = ev[idx].astype(bool)
             d = np.diff(state.astype(np.int8))
-            ups = list(np.nonzero(d == 1)[0] + 1)
-            downs = list(np.nonzero(d == -1)[0] + 1)
+            ups = np.nonzero(d == 1)[0] + 1
+            downs = np.nonzero(d == -1)[0] + 1
             if state[0]:
-                ups = [0] + ups
+                ups = np.concatenate([[0], ups])
             if state[-1]:
-                downs = downs + [num_frames - 1]
-            for u, dn in zip(ups, downs):
-                region = Segment(timestamps[u] - self.pad_onset, timestamps[dn] + self.pad_offset)
-                active[region, track] = label
+                downs = np.concatenate([downs, [num_frames - 1]])
+            m = min(len(ups), len(downs))
+            col_start.append(timestamps[ups[:m]] - self.pad_onset)
+            col_end.append(timestamps[downs[:m]] + self.pad_offset)
+            col_track += [track] * m
+            col_label += [label] * m
+        if col_start:
+            active = Annotation.from_columns(np.concatenate(col_start), np.concatenate(col_end),
+                                             col_track, col_label)
+        else:
+            active = Annotation()
         if self.pad_offset > 0.0 or self.pad_onset > 0.0 or self.min_duration_off > 0.0:
             active = active.support(collar=self.min_duration_off)
         if self.min_duration_on > 0:

@@ -50,7 +50,12 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     ws = torch.empty(lib.pa_linkage_workspace_bytes(n), dtype=torch.uint8, device=device)
     ffi.check(lib.pa_linkage_centroid_f64(ffi.ptr(cond), n, ffi.ptr(Z), ffi.ptr(ws), ws.numel(),
                                           ffi.stream()), "pa_linkage_centroid_f64")
+    global last_linkage_stats
+    last_linkage_stats = ws[-64:].view(torch.int64).cpu().numpy()   # development counters
     return Z.cpu().numpy()
+
+
+last_linkage_stats = None
 
 
 def cdist(A: np.ndarray, B: np.ndarray, metric: str = "cosine", device=None) -> np.ndarray:

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 import textwrap
+import time
 import warnings
 from dataclasses import dataclass
 from typing import Any, Callable, Mapping, Optional
@@ -220,7 +221,13 @@ class SpeakerDiarization(Pipeline):
         if self._expects_num_speakers and num_speakers is None:
             raise ValueError(f"num_speakers must be provided when using {self.klustering} clustering")
 
+        marks = [("start", time.perf_counter())]
+
+        def mark(name):
+            marks.append((name, time.perf_counter()))
+
         waveform = self._load(file)
+        mark("load")
         shard = parallel.current_shard()
         sr = self._audio.sample_rate
         window = self._segmentation.model.audio.get_num_samples(self._segmentation.duration)
@@ -231,6 +238,7 @@ class SpeakerDiarization(Pipeline):
 
         segmentations = self.get_segmentations(file, hook=hook, waveform=waveform,
                                                chunk_range=chunk_range)
+        mark("segmentation")
         if shard.world_size == 1:
             hook("segmentation", segmentations)
         num_chunks, num_frames, local_num_speakers = segmentations.data.shape
@@ -255,6 +263,7 @@ class SpeakerDiarization(Pipeline):
         dev_seg = self._device_segmentation(binarized_segmentations)
         count = frame_ops.speaker_count(dev_seg, binarized_segmentations.sliding_window,
                                         self._segmentation.model.receptive_field)
+        mark("speaker_counting")
         hook("speaker_counting", count)
 
         if np.nanmax(count.data) == 0.0:
@@ -268,6 +277,7 @@ class SpeakerDiarization(Pipeline):
             embeddings = self.get_embeddings(file, binarized_segmentations,
                                              exclude_overlap=self.embedding_exclude_overlap, hook=hook,
                                              waveform=waveform)
+        mark("embeddings")
         hook("embeddings", embeddings)
 
         active_frames, clean_frames = (t.cpu().numpy() for t in self._chunk_stats(dev_seg))
@@ -275,6 +285,7 @@ class SpeakerDiarization(Pipeline):
             embeddings=embeddings, segmentations=binarized_segmentations, num_clusters=num_speakers,
             min_clusters=min_speakers, max_clusters=max_speakers, file=file,
             frames=self._segmentation.model.receptive_field, num_clean_frames=clean_frames)
+        mark("clustering")
         num_different_speakers = np.max(hard_clusters) + 1
         if num_different_speakers < min_speakers or num_different_speakers > max_speakers:
             warnings.warn(textwrap.dedent(f"""
@@ -292,6 +303,7 @@ class SpeakerDiarization(Pipeline):
                                                 self._segmentation.model.receptive_field,
                                                 hard_clusters, count.data)
         discrete_diarization = reconstructor.discretize()
+        mark("reconstruction")
         hook("discrete_diarization", discrete_diarization)
         diarization = to_annotation(discrete_diarization, min_duration_on=0.0,
                                     min_duration_off=self.segmentation.min_duration_off)
@@ -309,6 +321,9 @@ class SpeakerDiarization(Pipeline):
                    for label, expected_label in zip(diarization.labels(), self.classes())}
         diarization = diarization.rename_labels(mapping=mapping)
         exclusive_diarization = exclusive_diarization.rename_labels(mapping=mapping)
+        mark("annotation")
+        # wall-clock per stage of the last call (host clock, no device synchronisation)
+        self.timings = {b[0]: b[1] - a[1] for a, b in zip(marks[:-1], marks[1:])}
 
         if centroids is None:
             output = DiarizeOutput(speaker_diarization=diarization,

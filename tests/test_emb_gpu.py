@@ -60,26 +60,31 @@ def test_conv3x3_configs(gpu_device):
     lib = ffi.load()
     g = torch.Generator().manual_seed(11)
     # (cin, cout, H, W, stride): one per kernel instantiation + ragged edges
-    cases = [(32, 32, 80, 70, 1), (64, 64, 40, 45, 1), (128, 128, 20, 37, 1), (256, 256, 10, 70, 1),
-             (32, 64, 80, 71, 2), (128, 256, 20, 67, 2), (64, 128, 40, 50, 2)]
-    for cin, cout, H, W, s in cases:
-        B = 2
+    # the kernel is persistent (grid = resident workgroups, each loops over tiles with a cross-tile
+    # prefetch): the B = 48 / 150 cases give every workgroup several tiles, also without a residual
+    cases = [(32, 32, 80, 70, 1, 2, True), (64, 64, 40, 45, 1, 2, True), (128, 128, 20, 37, 1, 2, True),
+             (256, 256, 10, 70, 1, 2, True), (32, 64, 80, 71, 2, 2, True), (128, 256, 20, 67, 2, 2, True),
+             (64, 128, 40, 50, 2, 2, True), (32, 32, 80, 70, 1, 48, True), (32, 64, 80, 71, 2, 48, False),
+             (256, 256, 10, 70, 1, 150, False), (64, 64, 40, 45, 1, 40, True)]
+    for cin, cout, H, W, s, B, use_res in cases:
         x = torch.randn(B, cin, H, W, generator=g)
         wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
         sh = torch.randn(cout, generator=g)
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         res = torch.randn(B, cout, Ho, Wo, generator=g)
-        ref = F.relu(F.conv2d(x.double(), wt.double(), stride=s, padding=1) + sh.double().view(1, -1, 1, 1)
-                     + res.double()).float()
+        ref = F.conv2d(x, wt, stride=s, padding=1) + sh.view(1, -1, 1, 1)
+        ref = F.relu(ref + res if use_res else ref)
         xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
         wd = wt.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous().to(gpu_device)
         rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device)
         shd = sh.to(gpu_device)
         y = torch.full((B, Ho, Wo, cout), float("nan"), device=gpu_device)
-        ffi.check(lib.pa_conv3x3(ffi.ptr(xd), B, H, W, cin, ffi.ptr(wd), ffi.ptr(shd), ffi.ptr(rd),
-                                 ffi.ptr(y), cout, s, 1, ffi.stream()), "conv3x3")
+        ffi.check(lib.pa_conv3x3(ffi.ptr(xd), B, H, W, cin, ffi.ptr(wd), ffi.ptr(shd),
+                                 ffi.ptr(rd) if use_res else None, ffi.ptr(y), cout, s, 1, ffi.stream()),
+                  "conv3x3")
         torch.cuda.synchronize()
-        e = report(f"conv3x3_{cin}_{cout}_{H}x{W}_s{s}", y.permute(0, 3, 1, 2), ref)
+        e = report(f"conv3x3_{cin}_{cout}_{H}x{W}_s{s}_B{B}", y.permute(0, 3, 1, 2), ref)
+        assert not torch.isnan(y).any()
         assert e < 1e-4 * ref.abs().max().item()
 
 
