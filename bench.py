@@ -162,9 +162,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    exchange = dist.is_initialized()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
@@ -186,7 +188,7 @@ def main():
     def step():
         timer.start()
         out = pipeline(file, hook=timer)
-        if world > 1:
+        if exchange:
             # exchange step of configs[4]: per-chunk hard segmentations + embeddings of every file
             payload = pipeline.last_exchange_payload(device)
             gathered = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=device)
@@ -194,7 +196,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,7 +211,7 @@ def main():
             stage_sum[k] = stage_sum.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -237,17 +239,27 @@ def main():
                              "gbs": round(r["bytes"] / ms / 1e6, 1) if ms > 0 else None}
         dom = max(prof, key=lambda k: prof[k]["ms"])
         r = prof[dom]
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+        # (profiles/r1_traffic.json, produced by tools/pmc_traffic.py; separate FETCH_SIZE / WRITE_SIZE
+        # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fp:
+                traffic = json.load(fp).get(dom, {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         if dom in MFMA_KERNELS:
             ach = r["flops"] / r["ms"] / 1e9
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
                     "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4),
                     "algorithmic_gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3)}
         else:
             ach = r["bytes"] / r["ms"] / 1e6
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4)}
         total_hours = args.hours * world * args.steps
         line = {
@@ -275,7 +287,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 
