@@ -133,6 +133,8 @@ typedef struct pa_emb_weights {
   const float* blk_shift1[PA_MAX_RES_BLOCKS]; /* [cout] */
   const float* blk_w2[PA_MAX_RES_BLOCKS];     /* [9][cout][cout] */
   const float* blk_shift2[PA_MAX_RES_BLOCKS];
+  const float* blk_u1[PA_MAX_RES_BLOCKS];     /* [16][cout][cin] Winograd F(2x2,3x3) image G g G^T of w1, or NULL */
+  const float* blk_u2[PA_MAX_RES_BLOCKS];     /* same for w2; used for stride-1 convolutions when not NULL */
   const float* blk_wsc[PA_MAX_RES_BLOCKS];    /* [cout][cin] 1x1 stride-2 shortcut or NULL */
   const float* blk_shiftsc[PA_MAX_RES_BLOCKS];
   const float* seg1_w; /* [embed_dim][2 * planes[3] * num_mel/8] */
@@ -159,6 +161,9 @@ int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, con
                    float* out, void* stream);
 int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, const float* shift,
                const float* R, float* Y, int cout, int stride, int relu, void* stream);
+/* the same stride-1 convolution through Winograd F(2x2,3x3); U: [16][cout][cin] = G g G^T, xi = 4a + b */
+int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                    const float* R, float* Y, int cout, int relu, void* stream);
 int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream);
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream);

@@ -1,0 +1,327 @@
+// Winograd F(2x2, 3x3) for the stride-1 BasicBlock convolutions of the WeSpeaker ResNet on gfx950
+// (reference: models/embedding/wespeaker/resnet.py:84-145; what MIOpen, the reference's backend, also
+//  selects for fp32 3x3 convolutions).  2.25x fewer multiplies than the direct form at true fp32:
+//
+//     Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A         per 2x2 output tile, 4x4 input patch d
+//
+//   * U = G g G^T (BatchNorm scale folded into g) is precomputed on the host in float64 -> [16][cout][cin]
+//   * a workgroup (4 waves, 2 workgroups per CU) owns TR x 16*TCG Winograd tiles x 32 output channels;
+//     wave w owns 16 consecutive tiles of one tile row: lane (t = lane & 15, g = lane >> 4) transforms
+//     the 4x4 patch of tile t for the channel quad g IN REGISTERS (V = B^T d B, 32 adds per channel) --
+//     V never touches LDS -- and feeds it straight to v_mfma_f32_16x16x4_f32 as the A operand: for each
+//     of the 16 transform points xi, D[tile][cout] += V_xi[tile][cin] * U_xi[cin][cout];
+//   * the accumulators of the 16 points (16 x 2 cout groups x 4 VGPRs) stay in registers over the whole
+//     cin loop; the inverse transform A^T M A is lane-local because a lane holds all 16 points of its
+//     (tile, cout) entries; epilogue = + BN shift (+ residual) (+ ReLU), branch-free buffer stores;
+//   * staging is LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing through VGPRs, the
+//     hardware bounds check zero-fills the halo): the input patch, de-interleaved by column parity so
+//     that the stride-2 tile walk reads consecutive LDS rows, and the U slab [16][32][16 cin].  Rows are
+//     64 B (16 channels) unpadded; the 16-B quad of row r sits at slot (g + 2*((r>>2)&1)) & 3, which makes
+//     every ds_read_b128 of 16 consecutive rows bank-conflict free (brute-forced over all alignments).
+// Numerics: fp32 throughout; the transforms only add/subtract and the 1/2 factors of G are applied in
+// float64 on the host; error ~3x the direct form's (tests: |err| <= 1e-4 max|ref| per conv, end to end).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace pa {
+
+constexpr int WCB = 16;   // input channels per stage (one 64-B LDS row)
+constexpr int W_BN = 32;  // output channels per workgroup
+constexpr int W_T = 256;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int TR, int TCG>
+struct WinoGeom {
+  static_assert(TR * TCG == 4, "4 waves");
+  static constexpr int PH = 2 * TR + 2;          // patch rows
+  static constexpr int PW = 2 * 16 * TCG + 2;    // patch cols
+  static constexpr int PWH = PW / 2;             // entries per column parity
+  static constexpr int PROWS = PH * 2 * PWH;     // LDS rows of the patch
+  static constexpr int PINSTR = (PROWS + 15) / 16;  // 1-KB DMA pieces
+  static constexpr int PATCH = PINSTR * 16 * WCB;   // floats
+  static constexpr int UINSTR = 16 * W_BN / 16;     // 32 pieces
+  static constexpr int USLAB = 16 * W_BN * WCB;     // floats
+};
+
+// physical 16-B slot of logical channel quad g in LDS row r
+__device__ __forceinline__ int wslot(int r, int g) { return (g + 2 * ((r >> 2) & 1)) & 3; }
+
+struct WinoTile {
+  int b, n0, y0, x0;
+};
+
+// LDS-DMA of one stage (16 input channels from c0) of tile q into `patch` / `uslab`:
+// piece k fills LDS rows 16k .. 16k+15; lane l -> row 16k + (l>>2), physical slot l&3.
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_issue(const float* __restrict__ X, const float* __restrict__ U,
+                                           int H, int W, int CIN, int COUT, const WinoTile& q, int c0,
+                                           float* patch, float* uslab, int lane, int wv) {
+  using G = WinoGeom<TR, TCG>;
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(U + (long)q.n0 * CIN), 0, (16 * COUT - q.n0) * CIN * 4, 0x00020000);
+#pragma unroll
+  for (int k = wv; k < G::PINSTR; k += 4) {
+    const int row = 16 * k + (lane >> 2);
+    const int gq = ((lane & 3) - 2 * ((row >> 2) & 1)) & 3;  // logical quad stored in this slot
+    const int pr = row / G::PWH, idx = row % G::PWH;         // pr = py*2 + parity
+    const int py = pr >> 1, px = 2 * idx + (pr & 1);
+    const int iy = q.y0 - 1 + py, ix = q.x0 - 1 + px;
+    const int off = (row < G::PROWS && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                        ? ((iy * W + ix) * CIN + 4 * gq) * 4
+                        : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(patch + 256 * k), 16, off, c0 * 4, 0, 0);
+  }
+#pragma unroll
+  for (int k = wv; k < G::UINSTR; k += 4) {
+    const int row = 16 * k + (lane >> 2);  // xi * 32 + n
+    const int gq = ((lane & 3) - 2 * ((row >> 2) & 1)) & 3;
+    const int xi = row / W_BN, n = row % W_BN;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (lds_ptr_t)(uslab + 256 * k), 16,
+                                             ((xi * COUT + n) * CIN + 4 * gq) * 4, c0 * 4, 0, 0);
+  }
+}
+
+// one stage of MFMA work on the landed LDS buffers
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_compute(const float* patch, const float* uslab, f32x4 (&acc)[16][2],
+                                             int t, int g, int wr, int wc) {
+  using G = WinoGeom<TR, TCG>;
+  // ---- input transform V = B^T d B of tile (wr, 16*wc + t) for channels 4g..4g+3, in registers
+  f32x4 v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = ((2 * wr + i) * 2 + (j & 1)) * G::PWH + 16 * wc + t + (j >> 1);
+      d[j] = *reinterpret_cast<const f32x4*>(patch + row * WCB + 4 * wslot(row, g));
+    }
+    v[i][0] = d[0] - d[2];
+    v[i][1] = d[1] + d[2];
+    v[i][2] = d[2] - d[1];
+    v[i][3] = d[1] - d[3];
+  }
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    const f32x4 r0 = v[0][bb], r1 = v[1][bb], r2 = v[2][bb], r3 = v[3][bb];
+    v[0][bb] = r0 - r2;
+    v[1][bb] = r1 + r2;
+    v[2][bb] = r2 - r1;
+    v[3][bb] = r1 - r3;
+  }
+  // ---- 16 transform points x 2 cout groups x 4 k-steps; B fragments one point ahead
+  f32x4 bf[2][2];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg) {
+    const int row = 16 * cg + t;
+    bf[0][cg] = *reinterpret_cast<const f32x4*>(uslab + row * WCB + 4 * wslot(row, g));
+  }
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) {
+    if (xi + 1 < 16) {
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const int row = (xi + 1) * W_BN + 16 * cg + t;
+        bf[(xi + 1) & 1][cg] = *reinterpret_cast<const f32x4*>(uslab + row * WCB + 4 * wslot(row, g));
+      }
+    }
+    const f32x4 av = v[xi >> 2][xi & 3];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) {
+      const f32x4 bv = bf[xi & 1][cg];
+      acc[xi][cg] = MFMA16(av[0], bv[0], acc[xi][cg]);
+      acc[xi][cg] = MFMA16(av[1], bv[1], acc[xi][cg]);
+      acc[xi][cg] = MFMA16(av[2], bv[2], acc[xi][cg]);
+      acc[xi][cg] = MFMA16(av[3], bv[3], acc[xi][cg]);
+    }
+  }
+}
+
+// inverse transform + epilogue.  acc[xi][cg][r]: cout n0 + 16cg + t, tile column 16wc + 4g + r of tile
+// row wr: outputs (y0 + 2wr + p, x0 + 2(16wc + 4g + r) + qq), p, qq in {0, 1}.
+template <bool HAS_R>
+__device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
+                                              int COUT, const float* __restrict__ shift,
+                                              const float* __restrict__ R, float* __restrict__ Y,
+                                              int relu, int t, int g, int wr, int wc) {
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+      Y + (long)q.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(HAS_R ? R + (long)q.b * H * W * COUT : Y), 0, H * W * COUT * 4, 0x00020000);
+  constexpr int NG = 8;  // groups (cg, r) of 4 outputs
+  int off[2][4];
+  float rv[2][4];
+  auto goffs = [&](int gi, int* o) {
+    const int cg = gi >> 2, r = gi & 3;
+    const int n = q.n0 + 16 * cg + t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int y = q.y0 + 2 * wr + (e >> 1), x = q.x0 + 2 * (16 * wc + 4 * g + r) + (e & 1);
+      o[e] = (y < H && x < W) ? ((y * W + x) * COUT + n) * 4 : OOB;
+    }
+  };
+  auto gres = [&](const int* o, float* vv) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      vv[e] = HAS_R ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrd, o[e], 0, 0)) : 0.f;
+  };
+  goffs(0, off[0]);
+  gres(off[0], rv[0]);
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    if (gi + 1 < NG) {
+      goffs(gi + 1, off[(gi + 1) & 1]);
+      gres(off[(gi + 1) & 1], rv[(gi + 1) & 1]);
+    }
+    const int cg = gi >> 2, r = gi & 3;
+    const float sh = shift[q.n0 + 16 * cg + t];
+    float s[4], dd[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      s[a] = acc[4 * a + 0][cg][r] + acc[4 * a + 1][cg][r] + acc[4 * a + 2][cg][r];
+      dd[a] = acc[4 * a + 1][cg][r] - acc[4 * a + 2][cg][r] - acc[4 * a + 3][cg][r];
+    }
+    float o4[4];
+    o4[0] = s[0] + s[1] + s[2];
+    o4[1] = dd[0] + dd[1] + dd[2];
+    o4[2] = s[1] - s[2] - s[3];
+    o4[3] = dd[1] - dd[2] - dd[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float vv = o4[e] + sh + rv[gi & 1][e];
+      if (relu) vv = fmaxf(vv, 0.f);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, vv), ysrd, off[gi & 1][e], 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw, int n_tiles, int th,
+                                                int tw) {
+  WinoTile o;
+  const int pix = q % tiles_hw, rest = q / tiles_hw;
+  o.n0 = (rest % n_tiles) * W_BN;
+  o.b = rest / n_tiles;
+  o.y0 = (pix / tiles_w) * th;
+  o.x0 = (pix % tiles_w) * tw;
+  return o;
+}
+
+// DB = false: one LDS buffer, two workgroups per CU cover each other's DMA waits.
+// DB = true : two LDS buffers, one workgroup per CU; the DMA of stage s+1 (next channel block, or the
+//             first block of the next tile) flies under the MFMAs of stage s; one barrier per stage.
+template <int TR, int TCG, bool HAS_R, bool DB>
+__global__ __launch_bounds__(W_T, DB ? 1 : 2) void k_conv3x3_wino(
+    const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
+    const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
+    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles) {
+  using G = WinoGeom<TR, TCG>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = G::PATCH + G::USLAB;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int wr = wv / TCG, wc = wv % TCG;  // tile row / 16-tile column group of this wave
+
+  int q = blockIdx.x;
+  if (q >= total_tiles) return;
+  WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG);
+  int stage = 0;
+  if (DB) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, 0, smem, smem + G::PATCH, lane, wv);
+  for (; q < total_tiles; q += gridDim.x) {
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[xi][cg][r] = 0.f;
+    const int qn = q + gridDim.x;
+    WinoTile nxt = cur;
+    if (qn < total_tiles) nxt = wino_decode(qn, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG);
+
+    for (int c0 = 0; c0 < CIN; c0 += WCB, ++stage) {
+      if (DB) {
+        float* pb = smem + (stage & 1) * BUF;
+        float* nb = smem + ((stage + 1) & 1) * BUF;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of stage `stage` landed
+        __syncthreads();  // ... everybody's did, and everybody finished reading the other buffer
+        if (c0 + WCB < CIN) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0 + WCB, nb, nb + G::PATCH, lane, wv);
+        else if (qn < total_tiles) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, nxt, 0, nb, nb + G::PATCH, lane, wv);
+        wino_compute<TR, TCG>(pb, pb + G::PATCH, acc, t, g, wr, wc);
+      } else {
+        __syncthreads();  // every wave is done reading the previous stage
+        wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0, smem, smem + G::PATCH, lane, wv);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        wino_compute<TR, TCG>(smem, smem + G::PATCH, acc, t, g, wr, wc);
+      }
+    }
+    wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc);
+    cur = nxt;
+  }
+}
+
+template <int TR, int TCG, bool HAS_R, bool DB>
+static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
+                         const float* R, float* Y, int COUT, int relu, hipStream_t st) {
+  using G = WinoGeom<TR, TCG>;
+  const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
+  const size_t lds = (size_t)(G::PATCH + G::USLAB) * sizeof(float) * (DB ? 2 : 1);
+  static int resident = 0;
+  if (!resident) {
+    (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R, DB>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, DB>, W_T,
+                                                     lds) != hipSuccess || per_cu < 1)
+      per_cu = DB ? 1 : 2;
+    resident = cus * per_cu;
+  }
+  const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
+  const long total = (long)tiles_hw * n_tiles * B;
+  const int grid = (int)(total < resident ? total : resident);
+  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, DB>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
+                     U, shift, R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total);
+  return 0;
+}
+
+template <int TR, int TCG>
+static int launch_wino(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
+                       const float* R, float* Y, int COUT, int relu, hipStream_t st) {
+  static const int db = getenv("PA_WINO_DB") ? atoi(getenv("PA_WINO_DB")) : 0;  // measured: 2 WG/CU wins
+  if (db)
+    return R != nullptr ? launch_wino_r<TR, TCG, true, true>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                        : launch_wino_r<TR, TCG, false, true>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
+  return R != nullptr ? launch_wino_r<TR, TCG, true, false>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                      : launch_wino_r<TR, TCG, false, false>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
+}
+
+}  // namespace pa
+
+extern "C" {
+
+// conv3x3, stride 1, pad 1, via Winograd F(2x2,3x3): Y = [relu](conv(X) + shift [+ R]).
+// U: [16][cout][cin] = G g G^T (xi = 4a + b), BatchNorm scale folded.
+int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                    const float* R, float* Y, int cout, int relu, void* stream) {
+  if (B <= 0) return 0;
+  PA_REQUIRE(cin % pa::WCB == 0 && cout % pa::W_BN == 0, "pa_conv3x3_wino: cin %% 16 and cout %% 32 required");
+  // algorithmic work = the direct convolution's (the reference's operation), not the reduced multiply count
+  pa::ProfScope prof("k_conv3x3", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
+                     4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
+  hipStream_t st = (hipStream_t)stream;
+  // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that wastes the fewest rows
+  if (H % 8 == 0 || H > 24) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  else if (H % 4 == 0 || H > 12) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  else pa::launch_wino<1, 4>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  PA_CHECK_LAUNCH("pa_conv3x3_wino");
+  return 0;
+}
+
+}  // extern "C"

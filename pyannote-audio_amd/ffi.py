@@ -45,6 +45,7 @@ class EmbWeights(C.Structure):
         ("stem_w", c_fp), ("stem_shift", c_fp),
         ("blk_w1", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift1", c_fp * PA_MAX_RES_BLOCKS),
         ("blk_w2", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift2", c_fp * PA_MAX_RES_BLOCKS),
+        ("blk_u1", c_fp * PA_MAX_RES_BLOCKS), ("blk_u2", c_fp * PA_MAX_RES_BLOCKS),
         ("blk_wsc", c_fp * PA_MAX_RES_BLOCKS), ("blk_shiftsc", c_fp * PA_MAX_RES_BLOCKS),
         ("seg1_w", c_fp), ("seg1_b", c_fp),
     ]
@@ -110,6 +111,8 @@ _OPTIONAL: list[tuple] = [
     ("pa_resnet_stem", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp], C.c_int),
     ("pa_conv3x3", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
                     C.c_int, c_fp], C.c_int),
+    ("pa_conv3x3_wino", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
+                         c_fp], C.c_int),
     ("pa_gather_s2", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_pdist_f64", [c_fp, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_cdist_cosine_f64", [c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),

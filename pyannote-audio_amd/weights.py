@@ -10,6 +10,9 @@ State-dict layout accepted (core/model.py:244-262):
 """
 from __future__ import annotations
 
+import os
+from typing import Optional
+
 import ctypes as C
 from itertools import combinations
 
@@ -191,6 +194,15 @@ def kaldi_mel_banks(num_bins: int = 80, padded: int = 512, sample_freq: float = 
     return torch.nn.functional.pad(bins, (0, 1)).contiguous()
 
 
+def winograd_weights(cw: torch.Tensor) -> torch.Tensor:
+    """(cout, cin, 3, 3) -> [16][cout][cin] float32: U = G g G^T of Winograd F(2x2, 3x3), computed in
+    float64 (xi = 4a + b indexes the 4x4 transform domain)."""
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+                     dtype=torch.float64)
+    U = torch.einsum("ap,oipq,bq->aboi", G, cw.double(), G)
+    return U.reshape(16, cw.shape[0], cw.shape[1]).float().contiguous()
+
+
 def _fold_bn(sd: dict, prefix: str, eps: float = 1e-5):
     scale = sd[prefix + ".weight"] / torch.sqrt(sd[prefix + ".running_var"] + eps)
     shift = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale
@@ -203,7 +215,10 @@ class EmbeddingPack:
     shortcut.1}, resnet.seg_1."""
 
     def __init__(self, state_dict: dict, device: torch.device, num_blocks=(3, 4, 6, 3),
-                 num_mel: int = 80, sample_rate: int = 16000):
+                 num_mel: int = 80, sample_rate: int = 16000, winograd: Optional[bool] = None):
+        if winograd is None:
+            winograd = os.environ.get("PA_WINOGRAD", "1") != "0"
+        self.winograd = winograd
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
         self.device = device
         self._keep: list[torch.Tensor] = []
@@ -245,6 +260,9 @@ class EmbeddingPack:
                     img = cw.permute(2, 3, 0, 1).reshape(9, cw.shape[0], cw.shape[1])
                     getattr(w, f"blk_w{j}")[blk] = self._up(img).value
                     getattr(w, f"blk_shift{j}")[blk] = self._up(sh).value
+                    stride = 2 if (j == 1 and i == 0 and l > 0) else 1
+                    if winograd and stride == 1:
+                        getattr(w, f"blk_u{j}")[blk] = self._up(winograd_weights(cw)).value
                 if f"{pre}.shortcut.0.weight" in sd:
                     sc, sh = _fold_bn(sd, f"{pre}.shortcut.1")
                     cw = sd[f"{pre}.shortcut.0.weight"][:, :, 0, 0] * sc.view(-1, 1)

@@ -146,3 +146,34 @@ def test_emb_forward_end_to_end(emb, gpu_device, B, N):
     assert torch.allclose(out.cpu(), ref, rtol=1e-3, atol=2e-4 * ref.abs().max().item())
     report(f"emb_unweighted_N{N}", out1, ref1)
     assert torch.allclose(out1.cpu(), ref1, rtol=1e-3, atol=2e-4 * ref1.abs().max().item())
+
+
+def test_conv3x3_winograd(gpu_device):
+    """pa_conv3x3_wino (Winograd F(2x2,3x3), fp32) vs torch conv2d: all ResNet34 channel configurations,
+    odd / ragged extents, with and without residual, enough images for several tiles per workgroup."""
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.weights import winograd_weights
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(12)
+    cases = [(32, 32, 80, 70, 2, True), (64, 64, 40, 45, 2, True), (128, 128, 20, 37, 2, False),
+             (256, 256, 10, 71, 2, True), (32, 32, 17, 9, 3, True), (64, 64, 1, 1, 2, False),
+             (32, 32, 80, 70, 48, True), (256, 256, 10, 125, 40, False), (128, 128, 20, 250, 20, True)]
+    for cin, cout, H, W, B, use_res in cases:
+        x = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+        sh = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, W, generator=g)
+        ref = F.conv2d(x, wt, stride=1, padding=1) + sh.view(1, -1, 1, 1)
+        ref = F.relu(ref + res if use_res else ref)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        ud = winograd_weights(wt).to(gpu_device)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        shd = sh.to(gpu_device)
+        y = torch.full((B, H, W, cout), float("nan"), device=gpu_device)
+        ffi.check(lib.pa_conv3x3_wino(ffi.ptr(xd), B, H, W, cin, ffi.ptr(ud), ffi.ptr(shd),
+                                      ffi.ptr(rd) if use_res else None, ffi.ptr(y), cout, 1, ffi.stream()),
+                  "conv3x3_wino")
+        torch.cuda.synchronize()
+        assert not torch.isnan(y).any(), (cin, cout, H, W, B)
+        e = report(f"wino3x3_{cin}_{cout}_{H}x{W}_B{B}", y.permute(0, 3, 1, 2), ref)
+        assert e < 1e-4 * ref.abs().max().item()
