@@ -51,18 +51,16 @@ struct WinoTile {
   int b, n0, y0, x0;
 };
 
-// LDS-DMA of one stage (16 input channels from c0) of tile q into `patch` / `uslab`:
+// LDS-DMA of one stage (16 input channels from c0) of tile q:
 // piece k fills LDS rows 16k .. 16k+15; lane l -> row 16k + (l>>2), physical slot l&3.
 template <int TR, int TCG>
-__device__ __forceinline__ void wino_issue(const float* __restrict__ X, const float* __restrict__ U,
-                                           int H, int W, int CIN, int COUT, const WinoTile& q, int c0,
-                                           float* patch, float* uslab, int lane, int wv) {
+__device__ __forceinline__ void wino_issue_patch(const float* __restrict__ X, int H, int W, int CIN,
+                                                 const WinoTile& q, int c0, float* patch, int lane,
+                                                 int wv) {
   using G = WinoGeom<TR, TCG>;
   constexpr int OOB = (int)0x80000000;
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(U + (long)q.n0 * CIN), 0, (16 * COUT - q.n0) * CIN * 4, 0x00020000);
 #pragma unroll
   for (int k = wv; k < G::PINSTR; k += 4) {
     const int row = 16 * k + (lane >> 2);
@@ -75,6 +73,14 @@ __device__ __forceinline__ void wino_issue(const float* __restrict__ X, const fl
                         : OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(patch + 256 * k), 16, off, c0 * 4, 0, 0);
   }
+}
+
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_issue_u(const float* __restrict__ U, int CIN, int COUT,
+                                             const WinoTile& q, int c0, float* uslab, int lane, int wv) {
+  using G = WinoGeom<TR, TCG>;
+  const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(U + (long)q.n0 * CIN), 0, (16 * COUT - q.n0) * CIN * 4, 0x00020000);
 #pragma unroll
   for (int k = wv; k < G::UINSTR; k += 4) {
     const int row = 16 * k + (lane >> 2);  // xi * 32 + n
@@ -85,13 +91,19 @@ __device__ __forceinline__ void wino_issue(const float* __restrict__ X, const fl
   }
 }
 
-// one stage of MFMA work on the landed LDS buffers
 template <int TR, int TCG>
-__device__ __forceinline__ void wino_compute(const float* patch, const float* uslab, f32x4 (&acc)[16][2],
-                                             int t, int g, int wr, int wc) {
+__device__ __forceinline__ void wino_issue(const float* __restrict__ X, const float* __restrict__ U,
+                                           int H, int W, int CIN, int COUT, const WinoTile& q, int c0,
+                                           float* patch, float* uslab, int lane, int wv) {
+  wino_issue_patch<TR, TCG>(X, H, W, CIN, q, c0, patch, lane, wv);
+  wino_issue_u<TR, TCG>(U, CIN, COUT, q, c0, uslab, lane, wv);
+}
+
+// input transform V = B^T d B of tile (wr, 16*wc + t) for channels 4g..4g+3, in registers
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_transform(const float* patch, f32x4 (&v)[4][4], int t, int g, int wr,
+                                               int wc) {
   using G = WinoGeom<TR, TCG>;
-  // ---- input transform V = B^T d B of tile (wr, 16*wc + t) for channels 4g..4g+3, in registers
-  f32x4 v[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x4 d[4];
@@ -113,7 +125,11 @@ __device__ __forceinline__ void wino_compute(const float* patch, const float* us
     v[2][bb] = r2 - r1;
     v[3][bb] = r1 - r3;
   }
-  // ---- 16 transform points x 2 cout groups x 4 k-steps; B fragments one point ahead
+}
+
+// 16 transform points x 2 cout groups x 4 k-steps; B fragments one point ahead
+__device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4][4], f32x4 (&acc)[16][2],
+                                          int t, int g) {
   f32x4 bf[2][2];
 #pragma unroll
   for (int cg = 0; cg < 2; ++cg) {
@@ -139,6 +155,14 @@ __device__ __forceinline__ void wino_compute(const float* patch, const float* us
       acc[xi][cg] = MFMA16(av[3], bv[3], acc[xi][cg]);
     }
   }
+}
+
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_compute(const float* patch, const float* uslab, f32x4 (&acc)[16][2],
+                                             int t, int g, int wr, int wc) {
+  f32x4 v[4][4];
+  wino_transform<TR, TCG>(patch, v, t, g, wr, wc);
+  wino_mfma(uslab, v, acc, t, g);
 }
 
 // inverse transform + epilogue.  acc[xi][cg][r]: cout n0 + 16cg + t, tile column 16wc + 4g + r of tile
@@ -211,17 +235,20 @@ __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw
   return o;
 }
 
-// DB = false: one LDS buffer, two workgroups per CU cover each other's DMA waits.
-// DB = true : two LDS buffers, one workgroup per CU; the DMA of stage s+1 (next channel block, or the
-//             first block of the next tile) flies under the MFMAs of stage s; one barrier per stage.
-template <int TR, int TCG, bool HAS_R, bool DB>
-__global__ __launch_bounds__(W_T, DB ? 1 : 2) void k_conv3x3_wino(
+// MODE 0: one LDS buffer, two workgroups per CU cover each other's DMA waits.
+// MODE 1: two LDS buffers, one workgroup per CU; the DMA of stage s+1 (next channel block, or the
+//         first block of the next tile) flies under the MFMAs of stage s; one barrier per stage.
+// (measured on the ResNet34 shapes: MODE 0 wins by 10-25 % -- two waves per SIMD hide the LDS and DMA
+//  latencies better than one wave with a prefetch; MODE 1 is kept selectable with PA_WINO_MODE=1)
+template <int TR, int TCG, bool HAS_R, int MODE>
+__global__ __launch_bounds__(W_T, MODE == 1 ? 1 : 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
     int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles) {
   using G = WinoGeom<TR, TCG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = G::PATCH + G::USLAB;
+  constexpr bool DB = MODE == 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int t = lane & 15, g = lane >> 4;
   const int wr = wv / TCG, wc = wv % TCG;  // tile row / 16-tile column group of this wave
@@ -265,28 +292,28 @@ __global__ __launch_bounds__(W_T, DB ? 1 : 2) void k_conv3x3_wino(
   }
 }
 
-template <int TR, int TCG, bool HAS_R, bool DB>
+template <int TR, int TCG, bool HAS_R, int MODE>
 static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                          const float* R, float* Y, int COUT, int relu, hipStream_t st) {
   using G = WinoGeom<TR, TCG>;
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
-  const size_t lds = (size_t)(G::PATCH + G::USLAB) * sizeof(float) * (DB ? 2 : 1);
+  const size_t lds = (size_t)(G::PATCH + G::USLAB) * (MODE == 1 ? 2 : 1) * sizeof(float);
   static int resident = 0;
   if (!resident) {
-    (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R, DB>,
+    (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R, MODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, DB>, W_T,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, MODE>, W_T,
                                                      lds) != hipSuccess || per_cu < 1)
-      per_cu = DB ? 1 : 2;
+      per_cu = MODE == 1 ? 1 : 2;
     resident = cus * per_cu;
   }
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
   const long total = (long)tiles_hw * n_tiles * B;
   const int grid = (int)(total < resident ? total : resident);
-  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, DB>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
+  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, MODE>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
                      U, shift, R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total);
   return 0;
 }
@@ -294,12 +321,13 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
 template <int TR, int TCG>
 static int launch_wino(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                        const float* R, float* Y, int COUT, int relu, hipStream_t st) {
-  static const int db = getenv("PA_WINO_DB") ? atoi(getenv("PA_WINO_DB")) : 0;  // measured: 2 WG/CU wins
-  if (db)
-    return R != nullptr ? launch_wino_r<TR, TCG, true, true>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
-                        : launch_wino_r<TR, TCG, false, true>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
-  return R != nullptr ? launch_wino_r<TR, TCG, true, false>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
-                      : launch_wino_r<TR, TCG, false, false>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
+  // tuning aid: PA_WINO_MODE = 0 single LDS buffer, 2 workgroups per CU (default) | 1 double buffer
+  static const int mode = getenv("PA_WINO_MODE") ? atoi(getenv("PA_WINO_MODE")) : 0;
+  if (mode == 1)
+    return R != nullptr ? launch_wino_r<TR, TCG, true, 1>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                        : launch_wino_r<TR, TCG, false, 1>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
+  return R != nullptr ? launch_wino_r<TR, TCG, true, 0>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                      : launch_wino_r<TR, TCG, false, 0>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
 }
 
 }  // namespace pa
@@ -313,7 +341,7 @@ int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U
   if (B <= 0) return 0;
   PA_REQUIRE(cin % pa::WCB == 0 && cout % pa::W_BN == 0, "pa_conv3x3_wino: cin %% 16 and cout %% 32 required");
   // algorithmic work = the direct convolution's (the reference's operation), not the reduced multiply count
-  pa::ProfScope prof("k_conv3x3", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
+  pa::ProfScope prof("k_conv3x3_wino", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
                      4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
   // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that wastes the fewest rows
