@@ -61,8 +61,11 @@ __device__ __forceinline__ void wino_issue_patch(const float* __restrict__ X, in
   constexpr int OOB = (int)0x80000000;
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+  const int swv = __builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
-  for (int k = wv; k < G::PINSTR; k += 4) {
+  for (int i = 0; i < (G::PINSTR + 3) / 4; ++i) {
+    const int k = swv + 4 * i;
+    if (k >= G::PINSTR) break;  // wave-uniform
     const int row = 16 * k + (lane >> 2);
     const int gq = ((lane & 3) - 2 * ((row >> 2) & 1)) & 3;  // logical quad stored in this slot
     const int pr = row / G::PWH, idx = row % G::PWH;         // pr = py*2 + parity
@@ -81,13 +84,17 @@ __device__ __forceinline__ void wino_issue_u(const float* __restrict__ U, int CI
   using G = WinoGeom<TR, TCG>;
   const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(U + (long)q.n0 * CIN), 0, (16 * COUT - q.n0) * CIN * 4, 0x00020000);
+  // row = 16k + r (r = lane >> 2) = xi * 32 + n  ->  xi = k >> 1, n = 16 (k & 1) + r: the k-dependent part of
+  // the address is wave-uniform and goes into the scalar offset; one VGPR serves all pieces
+  const int r = lane >> 2;
+  const int gq = ((lane & 3) - 2 * ((r >> 2) & 1)) & 3;  // logical quad stored in this slot
+  const int voff = (r * CIN + 4 * gq) * 4;
+  const int swv = __builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
-  for (int k = wv; k < G::UINSTR; k += 4) {
-    const int row = 16 * k + (lane >> 2);  // xi * 32 + n
-    const int gq = ((lane & 3) - 2 * ((row >> 2) & 1)) & 3;
-    const int xi = row / W_BN, n = row % W_BN;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (lds_ptr_t)(uslab + 256 * k), 16,
-                                             ((xi * COUT + n) * CIN + 4 * gq) * 4, c0 * 4, 0, 0);
+  for (int i = 0; i < G::UINSTR / 4; ++i) {
+    const int k = swv + 4 * i;
+    const int soff = (c0 + ((k >> 1) * COUT + 16 * (k & 1)) * CIN) * 4;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (lds_ptr_t)(uslab + 256 * k), 16, voff, soff, 0, 0);
   }
 }
 
@@ -127,42 +134,45 @@ __device__ __forceinline__ void wino_transform(const float* patch, f32x4 (&v)[4]
   }
 }
 
-// 16 transform points x 2 cout groups x 4 k-steps; B fragments one point ahead
+// 16 transform points x 2 cout groups x 4 k-steps; B fragments PF points ahead of their MFMAs.
+// TUNE bit 0: PF = 2 instead of 1; bit 1: raise the wave priority for the MFMA section.
+template <int TUNE>
 __device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4][4], f32x4 (&acc)[16][2],
                                           int t, int g) {
-  f32x4 bf[2][2];
+  constexpr int PF = (TUNE & 1) ? 2 : 1;
+  f32x4 bf[PF + 1][2];
+  // row = 32 xi + 16 cg + t: its swizzle bit ((row >> 2) & 1) = (t >> 2) & 1 does not depend on xi / cg,
+  // so every read is (lane base) + compile-time offset -> folded into the ds_read immediate
+  const float* ub = uslab + t * WCB + 4 * wslot(t, g);
+  auto load = [&](int xi) {
 #pragma unroll
-  for (int cg = 0; cg < 2; ++cg) {
-    const int row = 16 * cg + t;
-    bf[0][cg] = *reinterpret_cast<const f32x4*>(uslab + row * WCB + 4 * wslot(row, g));
-  }
+    for (int cg = 0; cg < 2; ++cg)
+      bf[xi % (PF + 1)][cg] = *reinterpret_cast<const f32x4*>(ub + (xi * W_BN + 16 * cg) * WCB);
+  };
+#pragma unroll
+  for (int xi = 0; xi < PF; ++xi) load(xi);
+  if (TUNE & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi) {
-    if (xi + 1 < 16) {
-#pragma unroll
-      for (int cg = 0; cg < 2; ++cg) {
-        const int row = (xi + 1) * W_BN + 16 * cg + t;
-        bf[(xi + 1) & 1][cg] = *reinterpret_cast<const f32x4*>(uslab + row * WCB + 4 * wslot(row, g));
-      }
-    }
+    if (xi + PF < 16) load(xi + PF);
     const f32x4 av = v[xi >> 2][xi & 3];
+    // alternate the two accumulators: a 16x16x4 MFMA issues every 32 cycles but its result is ready
+    // after 40, so back-to-back MFMAs on ONE accumulator would stall 8 cycles each
 #pragma unroll
-    for (int cg = 0; cg < 2; ++cg) {
-      const f32x4 bv = bf[xi & 1][cg];
-      acc[xi][cg] = MFMA16(av[0], bv[0], acc[xi][cg]);
-      acc[xi][cg] = MFMA16(av[1], bv[1], acc[xi][cg]);
-      acc[xi][cg] = MFMA16(av[2], bv[2], acc[xi][cg]);
-      acc[xi][cg] = MFMA16(av[3], bv[3], acc[xi][cg]);
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[xi][0] = MFMA16(av[ks], bf[xi % (PF + 1)][0][ks], acc[xi][0]);
+      acc[xi][1] = MFMA16(av[ks], bf[xi % (PF + 1)][1][ks], acc[xi][1]);
     }
   }
+  if (TUNE & 2) __builtin_amdgcn_s_setprio(0);
 }
 
-template <int TR, int TCG>
+template <int TR, int TCG, int TUNE>
 __device__ __forceinline__ void wino_compute(const float* patch, const float* uslab, f32x4 (&acc)[16][2],
                                              int t, int g, int wr, int wc) {
   f32x4 v[4][4];
   wino_transform<TR, TCG>(patch, v, t, g, wr, wc);
-  wino_mfma(uslab, v, acc, t, g);
+  wino_mfma<TUNE>(uslab, v, acc, t, g);
 }
 
 // inverse transform + epilogue.  acc[xi][cg][r]: cout n0 + 16cg + t, tile column 16wc + 4g + r of tile
@@ -238,16 +248,21 @@ __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw
 // MODE 0: one LDS buffer, two workgroups per CU cover each other's DMA waits.
 // MODE 1: two LDS buffers, one workgroup per CU; the DMA of stage s+1 (next channel block, or the
 //         first block of the next tile) flies under the MFMAs of stage s; one barrier per stage.
-// (measured on the ResNet34 shapes: MODE 0 wins by 10-25 % -- two waves per SIMD hide the LDS and DMA
-//  latencies better than one wave with a prefetch; MODE 1 is kept selectable with PA_WINO_MODE=1)
-template <int TR, int TCG, bool HAS_R, int MODE>
-__global__ __launch_bounds__(W_T, MODE == 1 ? 1 : 2) void k_conv3x3_wino(
+// MODE 2: one LDS buffer, two workgroups per CU, but the two halves of the buffer are recycled at
+//         different times: the patch is only read by the input transform, so the patch DMA of stage s+1
+//         is issued right after the transform of stage s and flies under its MFMAs; the (L2-resident) U
+//         slab of stage s is issued at the top of the stage and lands while the transform runs.
+// (measured on the ResNet34 shapes: MODE 0 beats MODE 1 by 10-25 % -- two waves per SIMD hide the LDS
+//  and DMA latencies better than one wave with a prefetch)
+template <int TR, int TCG, bool HAS_R, int MODE_TUNE>
+__global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
     int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles) {
   using G = WinoGeom<TR, TCG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = G::PATCH + G::USLAB;
+  constexpr int MODE = MODE_TUNE & 3, TUNE = MODE_TUNE >> 2;
   constexpr bool DB = MODE == 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int t = lane & 15, g = lane >> 4;
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(W_T, MODE == 1 ? 1 : 2) void k_conv3x3_wino(
   WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG);
   int stage = 0;
   if (DB) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, 0, smem, smem + G::PATCH, lane, wv);
+  if (MODE == 2) wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, 0, smem, lane, wv);
   for (; q < total_tiles; q += gridDim.x) {
     f32x4 acc[16][2];
 #pragma unroll
@@ -271,20 +287,36 @@ __global__ __launch_bounds__(W_T, MODE == 1 ? 1 : 2) void k_conv3x3_wino(
     if (qn < total_tiles) nxt = wino_decode(qn, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG);
 
     for (int c0 = 0; c0 < CIN; c0 += WCB, ++stage) {
-      if (DB) {
+      if (MODE == 2) {
+        float* us = smem + G::PATCH;
+        // (all waves passed the barrier that ends the previous stage: the U slab is free)
+        wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, us, lane, wv);
+        // vmcnt retires in order and every wave issues exactly UINSTR/4 U pieces: everything older --
+        // this wave's patch pieces of this stage -- has landed once only those remain outstanding
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (G::UINSTR / 4));
+        __syncthreads();  // the whole patch has landed
+        f32x4 v[4][4];
+        wino_transform<TR, TCG>(smem, v, t, g, wr, wc);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // this wave's U pieces landed (they flew under the transform)
+        __syncthreads();  // whole U slab landed; every wave is done reading the patch
+        if (c0 + WCB < CIN) wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0 + WCB, smem, lane, wv);
+        else if (qn < total_tiles) wino_issue_patch<TR, TCG>(X, H, W, CIN, nxt, 0, smem, lane, wv);
+        wino_mfma<TUNE>(us, v, acc, t, g);
+        __syncthreads();  // every wave is done reading the U slab
+      } else if (DB) {
         float* pb = smem + (stage & 1) * BUF;
         float* nb = smem + ((stage + 1) & 1) * BUF;
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of stage `stage` landed
         __syncthreads();  // ... everybody's did, and everybody finished reading the other buffer
         if (c0 + WCB < CIN) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0 + WCB, nb, nb + G::PATCH, lane, wv);
         else if (qn < total_tiles) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, nxt, 0, nb, nb + G::PATCH, lane, wv);
-        wino_compute<TR, TCG>(pb, pb + G::PATCH, acc, t, g, wr, wc);
+        wino_compute<TR, TCG, TUNE>(pb, pb + G::PATCH, acc, t, g, wr, wc);
       } else {
         __syncthreads();  // every wave is done reading the previous stage
         wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0, smem, smem + G::PATCH, lane, wv);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
-        wino_compute<TR, TCG>(smem, smem + G::PATCH, acc, t, g, wr, wc);
+        wino_compute<TR, TCG, TUNE>(smem, smem + G::PATCH, acc, t, g, wr, wc);
       }
     }
     wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc);
@@ -292,20 +324,21 @@ __global__ __launch_bounds__(W_T, MODE == 1 ? 1 : 2) void k_conv3x3_wino(
   }
 }
 
-template <int TR, int TCG, bool HAS_R, int MODE>
+template <int TR, int TCG, bool HAS_R, int MODE_TUNE>
 static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                          const float* R, float* Y, int COUT, int relu, hipStream_t st) {
   using G = WinoGeom<TR, TCG>;
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
+  constexpr int MODE = MODE_TUNE & 3;
   const size_t lds = (size_t)(G::PATCH + G::USLAB) * (MODE == 1 ? 2 : 1) * sizeof(float);
   static int resident = 0;
   if (!resident) {
-    (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R, MODE>,
+    (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, MODE>, W_T,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>, W_T,
                                                      lds) != hipSuccess || per_cu < 1)
       per_cu = MODE == 1 ? 1 : 2;
     resident = cus * per_cu;
@@ -313,7 +346,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
   const long total = (long)tiles_hw * n_tiles * B;
   const int grid = (int)(total < resident ? total : resident);
-  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, MODE>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
+  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
                      U, shift, R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total);
   return 0;
 }
@@ -321,13 +354,25 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
 template <int TR, int TCG>
 static int launch_wino(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                        const float* R, float* Y, int COUT, int relu, hipStream_t st) {
-  // tuning aid: PA_WINO_MODE = 0 single LDS buffer, 2 workgroups per CU (default) | 1 double buffer
+  // tuning aid: PA_WINO_MODE = 0 single LDS buffer, 2 workgroups per CU | 1 double buffer, 1 WG/CU |
+  //             2 = 0 + split recycling of patch / U.  Measured on the full pipeline: 0 is the fastest
+  //             (0.755 vs 0.733 audio-h/s for 2 and 0.627 for 1), hence the default.
   static const int mode = getenv("PA_WINO_MODE") ? atoi(getenv("PA_WINO_MODE")) : 0;
+  if (mode == 2)
+    return R != nullptr ? launch_wino_r<TR, TCG, true, 2>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                        : launch_wino_r<TR, TCG, false, 2>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
   if (mode == 1)
     return R != nullptr ? launch_wino_r<TR, TCG, true, 1>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
                         : launch_wino_r<TR, TCG, false, 1>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
-  return R != nullptr ? launch_wino_r<TR, TCG, true, 0>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
-                      : launch_wino_r<TR, TCG, false, 0>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
+  static const int tune = getenv("PA_WINO_TUNE") ? atoi(getenv("PA_WINO_TUNE")) : 0;
+#define PA_WINO_GO(MT)                                                                                      \
+  return R != nullptr ? launch_wino_r<TR, TCG, true, MT>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)  \
+                      : launch_wino_r<TR, TCG, false, MT>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+  if (tune == 1) PA_WINO_GO(4);
+  if (tune == 2) PA_WINO_GO(8);
+  if (tune == 3) PA_WINO_GO(12);
+  PA_WINO_GO(0);
+#undef PA_WINO_GO
 }
 
 }  // namespace pa

@@ -35,7 +35,8 @@ for (H, W, ci, co, s, res) in shapes:
     ffi.prof_enable(True)
     for _ in range(reps): run()
     torch.cuda.synchronize()
-    r = ffi.prof_report()["k_conv3x3"]
+    rep = ffi.prof_report()
+    r = rep.get("k_conv3x3_wino") or rep["k_conv3x3"]
     ffi.prof_enable(False)
     ms = r["ms"] / r["launches"]
     print(f"conv {H}x{W} {ci}->{co} s{s}: {ms:.3f} ms  {r['flops']/r['ms']/1e9:.1f} TFLOP/s "
