@@ -2,6 +2,9 @@
 (mirrors models/embedding/wespeaker/__init__.py:324-343 and the b3 interface of SURVEY.md 8b)."""
 from __future__ import annotations
 
+import os
+from typing import Optional
+
 import torch
 import torch.nn.functional as F
 
@@ -13,9 +16,11 @@ class EmbeddingEngine:
     """fbank -> ResNet34 -> weighted statistics pooling -> Linear over strided chunks of a
     device-resident waveform.  The backbone runs once per chunk; all S masks are pooled from it."""
 
-    def __init__(self, pack: EmbeddingPack, max_chunks: int = 64):
+    def __init__(self, pack: EmbeddingPack, max_chunks: Optional[int] = None):
         self.pack = pack
-        self.max_chunks = max_chunks   # ~31 MB of activations per 10 s chunk
+        # chunks per launch group: ~31 MB of activations per 10 s chunk -> 8 GB at 256 (measured: 64 -> 256
+        # = +2.6 % throughput, fewer launches and tails; tuning aid: PA_EMB_BATCH)
+        self.max_chunks = max_chunks or int(os.environ.get("PA_EMB_BATCH", "256"))
         self._ws = None
         self._idx_cache: dict = {}
 
