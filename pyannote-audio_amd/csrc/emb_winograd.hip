@@ -48,7 +48,7 @@ struct WinoGeom {
 __device__ __forceinline__ int wslot(int r, int g) { return (g + 2 * ((r >> 2) & 1)) & 3; }
 
 struct WinoTile {
-  int b, n0, y0, x0;
+  int b, n0, y0, x0, valid;
 };
 
 // LDS-DMA of one stage (16 input channels from c0) of tile q:
@@ -234,12 +234,22 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
   }
 }
 
+// Tile order is XCD-aware: workgroup w runs on XCD w % 8 (each XCD has its own L2), so tile q is decoded
+// as xcd = q % 8, r = q / 8 with the cout tile FASTEST in r: the n_tiles workgroups that read the same
+// input patch (same image, same pixel tile, different 32-cout slices) run side by side on ONE XCD and
+// the patch comes from HBM once instead of n_tiles times.  (pixel tile, image) = (r / n_tiles) * 8 + xcd;
+// the index space is padded to a multiple of 8 (pixel tile, image) pairs: padding tiles are computed on
+// the last real tile's data and not stored (valid = 0).
 __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw, int n_tiles, int th,
-                                                int tw) {
+                                                int tw, int num_pb) {
   WinoTile o;
-  const int pix = q % tiles_hw, rest = q / tiles_hw;
-  o.n0 = (rest % n_tiles) * W_BN;
-  o.b = rest / n_tiles;
+  const int xcd = q & 7, r = q >> 3;
+  int pb = (r / n_tiles) * 8 + xcd;
+  o.n0 = (r % n_tiles) * W_BN;
+  o.valid = pb < num_pb;
+  pb = pb < num_pb ? pb : num_pb - 1;
+  const int pix = pb % tiles_hw;
+  o.b = pb / tiles_hw;
   o.y0 = (pix / tiles_w) * th;
   o.x0 = (pix % tiles_w) * tw;
   return o;
@@ -258,7 +268,7 @@ template <int TR, int TCG, bool HAS_R, int MODE_TUNE>
 __global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
-    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles) {
+    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb) {
   using G = WinoGeom<TR, TCG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = G::PATCH + G::USLAB;
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_w
 
   int q = blockIdx.x;
   if (q >= total_tiles) return;
-  WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG);
+  WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
   int stage = 0;
   if (DB) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, 0, smem, smem + G::PATCH, lane, wv);
   if (MODE == 2) wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, 0, smem, lane, wv);
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_w
         for (int r = 0; r < 4; ++r) acc[xi][cg][r] = 0.f;
     const int qn = q + gridDim.x;
     WinoTile nxt = cur;
-    if (qn < total_tiles) nxt = wino_decode(qn, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG);
+    if (qn < total_tiles) nxt = wino_decode(qn, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
 
     for (int c0 = 0; c0 < CIN; c0 += WCB, ++stage) {
       if (MODE == 2) {
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_w
         wino_compute<TR, TCG, TUNE>(smem, smem + G::PATCH, acc, t, g, wr, wc);
       }
     }
-    wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc);
+    if (cur.valid) wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc);
     cur = nxt;
   }
 }
@@ -344,10 +354,11 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
     resident = cus * per_cu;
   }
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
-  const long total = (long)tiles_hw * n_tiles * B;
+  const long num_pb = (long)tiles_hw * B;                    // (pixel tile, image) pairs
+  const long total = ((num_pb + 7) / 8) * 8 * n_tiles;       // padded to whole XCD stripes
   const int grid = (int)(total < resident ? total : resident);
   hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
-                     U, shift, R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total);
+                     U, shift, R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, (int)num_pb);
   return 0;
 }
 
