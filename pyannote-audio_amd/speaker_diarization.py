@@ -221,6 +221,13 @@ class SpeakerDiarization(Pipeline):
         if self._expects_num_speakers and num_speakers is None:
             raise ValueError(f"num_speakers must be provided when using {self.klustering} clustering")
 
+        # no CPU path: every stage below runs through libpyannote_amd.so on a gfx950 device
+        from . import ffi
+        ffi.require_gpu()
+        device = getattr(self.clustering, "device", None)
+        if device is None or getattr(device, "type", None) != "cuda":
+            raise RuntimeError("SpeakerDiarization must be moved to the GPU first: "
+                               "pipeline.to(torch.device('cuda')) -- there is no CPU fallback")
         marks = [("start", time.perf_counter())]
 
         def mark(name):
