@@ -166,7 +166,7 @@ def test_pipeline_from_pretrained_contract(pipeline_dir):
         p([{"waveform": wav, "sample_rate": 16000, "uri": "a"},
            {"waveform": wav, "sample_rate": 16000, "uri": "a"}])
     if not torch.cuda.is_available():
-        with pytest.raises(RuntimeError, match="no CPU compute path"):
+        with pytest.raises(RuntimeError, match="no CPU"):
             p({"waveform": wav, "sample_rate": 16000})
 
 
