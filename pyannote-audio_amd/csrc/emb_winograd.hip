@@ -28,12 +28,13 @@ namespace pa {
 
 constexpr int WCB = 16;   // input channels per stage (one 64-B LDS row)
 constexpr int W_BN = 32;  // output channels per workgroup
-constexpr int W_T = 256;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int TR, int TCG>
 struct WinoGeom {
-  static_assert(TR * TCG == 4, "4 waves");
+  static constexpr int NWV = TR * TCG;            // waves per workgroup: one tile row x 16 tile cols each
+  static_assert(NWV == 4 || NWV == 8, "4 or 8 waves");
+  static constexpr int THREADS = 64 * NWV;
   static constexpr int PH = 2 * TR + 2;          // patch rows
   static constexpr int PW = 2 * 16 * TCG + 2;    // patch cols
   static constexpr int PWH = PW / 2;             // entries per column parity
@@ -63,8 +64,8 @@ __device__ __forceinline__ void wino_issue_patch(const float* __restrict__ X, in
       const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
   const int swv = __builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
-  for (int i = 0; i < (G::PINSTR + 3) / 4; ++i) {
-    const int k = swv + 4 * i;
+  for (int i = 0; i < (G::PINSTR + G::NWV - 1) / G::NWV; ++i) {
+    const int k = swv + G::NWV * i;
     if (k >= G::PINSTR) break;  // wave-uniform
     const int row = 16 * k + (lane >> 2);
     const int gq = ((lane & 3) - 2 * ((row >> 2) & 1)) & 3;  // logical quad stored in this slot
@@ -91,8 +92,8 @@ __device__ __forceinline__ void wino_issue_u(const float* __restrict__ U, int CI
   const int voff = (r * CIN + 4 * gq) * 4;
   const int swv = __builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
-  for (int i = 0; i < G::UINSTR / 4; ++i) {
-    const int k = swv + 4 * i;
+  for (int i = 0; i < G::UINSTR / G::NWV; ++i) {
+    const int k = swv + G::NWV * i;
     const int soff = (c0 + ((k >> 1) * COUT + 16 * (k & 1)) * CIN) * 4;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (lds_ptr_t)(uslab + 256 * k), 16, voff, soff, 0, 0);
   }
@@ -265,7 +266,7 @@ __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw
 // (measured on the ResNet34 shapes: MODE 0 beats MODE 1 by 10-25 % -- two waves per SIMD hide the LDS
 //  and DMA latencies better than one wave with a prefetch)
 template <int TR, int TCG, bool HAS_R, int MODE_TUNE>
-__global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_wino(
+__global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG == 4) ? 1 : 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
     int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb) {
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_w
         wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, us, lane, wv);
         // vmcnt retires in order and every wave issues exactly UINSTR/4 U pieces: everything older --
         // this wave's patch pieces of this stage -- has landed once only those remain outstanding
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (G::UINSTR / 4));
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (G::UINSTR / G::NWV));
         __syncthreads();  // the whole patch has landed
         f32x4 v[4][4];
         wino_transform<TR, TCG>(smem, v, t, g, wr, wc);
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(W_T, (MODE_TUNE & 3) == 1 ? 1 : 2) void k_conv3x3_w
         wino_compute<TR, TCG, TUNE>(pb, pb + G::PATCH, acc, t, g, wr, wc);
       } else {
         __syncthreads();  // every wave is done reading the previous stage
-        wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0, smem, smem + G::PATCH, lane, wv);
+        if (!(TUNE & 4) || stage == 0)  // (TUNE bit 2: measurement aid -- stage only once, results invalid)
+          wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0, smem, smem + G::PATCH, lane, wv);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         wino_compute<TR, TCG, TUNE>(smem, smem + G::PATCH, acc, t, g, wr, wc);
@@ -348,7 +350,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>, W_T,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>, G::THREADS,
                                                      lds) != hipSuccess || per_cu < 1)
       per_cu = MODE == 1 ? 1 : 2;
     resident = cus * per_cu;
@@ -357,7 +359,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   const long num_pb = (long)tiles_hw * B;                    // (pixel tile, image) pairs
   const long total = ((num_pb + 7) / 8) * 8 * n_tiles;       // padded to whole XCD stripes
   const int grid = (int)(total < resident ? total : resident);
-  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>), dim3(grid), dim3(W_T), lds, st, X, H, W, CIN,
+  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>), dim3(grid), dim3(G::THREADS), lds, st, X, H, W, CIN,
                      U, shift, R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, (int)num_pb);
   return 0;
 }
@@ -382,8 +384,16 @@ static int launch_wino(const float* X, int B, int H, int W, int CIN, const float
   if (tune == 1) PA_WINO_GO(4);
   if (tune == 2) PA_WINO_GO(8);
   if (tune == 3) PA_WINO_GO(12);
+  if (tune == 4) PA_WINO_GO(16);
   PA_WINO_GO(0);
 #undef PA_WINO_GO
+}
+
+template <int TR, int TCG>
+static int launch_wino8(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
+                        const float* R, float* Y, int COUT, int relu, hipStream_t st) {
+  return R != nullptr ? launch_wino_r<TR, TCG, true, 1>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                      : launch_wino_r<TR, TCG, false, 1>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
 }
 
 }  // namespace pa
@@ -400,8 +410,13 @@ int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U
   pa::ProfScope prof("k_conv3x3_wino", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
                      4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
-  // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that wastes the fewest rows
-  if (H % 8 == 0 || H > 24) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that wastes the fewest rows.
+  // PA_WINO_WG8=1 (tuning aid): tall maps use 8-wave workgroups with double-buffered LDS (one per CU, two
+  // waves per SIMD, DMA of the next stage under the MFMAs, U slab shared by twice as many tiles).
+  static const int wg8 = getenv("PA_WINO_WG8") ? atoi(getenv("PA_WINO_WG8")) : 0;
+  if (wg8 && H % 16 == 0) pa::launch_wino8<8, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  else if (wg8 && H % 8 == 0) pa::launch_wino8<4, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  else if (H % 8 == 0 || H > 24) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   else if (H % 4 == 0 || H > 12) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   else pa::launch_wino<1, 4>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   PA_CHECK_LAUNCH("pa_conv3x3_wino");
