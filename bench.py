@@ -290,7 +290,7 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(seg_o, emb_o, args.cpu_seconds)
         else:
             line["cpu_baseline"] = None

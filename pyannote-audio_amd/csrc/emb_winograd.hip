@@ -155,14 +155,14 @@ __device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4
   if (TUNE & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi) {
-    if (xi + PF < 16) load(xi + PF);
+    if (xi + PF < 16 && !(TUNE & 32)) load(xi + PF);
     const f32x4 av = v[xi >> 2][xi & 3];
     // alternate the two accumulators: a 16x16x4 MFMA issues every 32 cycles but its result is ready
     // after 40, so back-to-back MFMAs on ONE accumulator would stall 8 cycles each
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      acc[xi][0] = MFMA16(av[ks], bf[xi % (PF + 1)][0][ks], acc[xi][0]);
-      acc[xi][1] = MFMA16(av[ks], bf[xi % (PF + 1)][1][ks], acc[xi][1]);
+      acc[xi][0] = MFMA16(av[ks], bf[(TUNE & 32) ? 0 : xi % (PF + 1)][0][ks], acc[xi][0]);
+      acc[xi][1] = MFMA16(av[ks], bf[(TUNE & 32) ? 0 : xi % (PF + 1)][1][ks], acc[xi][1]);
     }
   }
   if (TUNE & 2) __builtin_amdgcn_s_setprio(0);
@@ -283,6 +283,12 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
   if (q >= total_tiles) return;
   WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
   int stage = 0;
+  f32x4 dbg_v[4][4];  // (measurement aids only)
+  if (TUNE & 48)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dbg_v[i][j] = f32x4{1.f, 1.f, 1.f, 1.f};
   if (DB) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, 0, smem, smem + G::PATCH, lane, wv);
   if (MODE == 2) wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, 0, smem, lane, wv);
   for (; q < total_tiles; q += gridDim.x) {
@@ -323,12 +329,19 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
         else if (qn < total_tiles) wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, nxt, 0, nb, nb + G::PATCH, lane, wv);
         wino_compute<TR, TCG, TUNE>(pb, pb + G::PATCH, acc, t, g, wr, wc);
       } else {
-        __syncthreads();  // every wave is done reading the previous stage
-        if (!(TUNE & 4) || stage == 0)  // (TUNE bit 2: measurement aid -- stage only once, results invalid)
+        // TUNE bits 2..5 are measurement aids (results invalid): 4 = stage LDS only once, 8 = no barriers,
+        // 16 = input transform only once, 32 = B fragments read only once
+        if (!(TUNE & 8) || stage == 0) __syncthreads();  // every wave is done reading the previous stage
+        if (!(TUNE & 4) || stage == 0)
           wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0, smem, smem + G::PATCH, lane, wv);
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        wino_compute<TR, TCG, TUNE>(smem, smem + G::PATCH, acc, t, g, wr, wc);
+        if (!(TUNE & 8) || stage == 0) __syncthreads();
+        if (TUNE & 48) {
+          if (!(TUNE & 16) || stage == 0) wino_transform<TR, TCG>(smem, dbg_v, t, g, wr, wc);
+          wino_mfma<TUNE>(smem + G::PATCH, dbg_v, acc, t, g);
+        } else {
+          wino_compute<TR, TCG, TUNE>(smem, smem + G::PATCH, acc, t, g, wr, wc);
+        }
       }
     }
     if (cur.valid) wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc);
@@ -385,6 +398,9 @@ static int launch_wino(const float* X, int B, int H, int W, int CIN, const float
   if (tune == 2) PA_WINO_GO(8);
   if (tune == 3) PA_WINO_GO(12);
   if (tune == 4) PA_WINO_GO(16);
+  if (tune == 12) PA_WINO_GO(48);
+  if (tune == 28) PA_WINO_GO(112);
+  if (tune == 60) PA_WINO_GO(240);
   PA_WINO_GO(0);
 #undef PA_WINO_GO
 }
