@@ -332,8 +332,11 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
         // TUNE bits 2..5 are measurement aids (results invalid): 4 = stage LDS only once, 8 = no barriers,
         // 16 = input transform only once, 32 = B fragments read only once
         if (!(TUNE & 8) || stage == 0) __syncthreads();  // every wave is done reading the previous stage
-        if (!(TUNE & 4) || stage == 0)
-          wino_issue<TR, TCG>(X, U, H, W, CIN, COUT, cur, c0, smem, smem + G::PATCH, lane, wv);
+        // (64 = patch staged only once, 128 = U slab staged only once)
+        if ((!(TUNE & 4) && !(TUNE & 64)) || stage == 0)
+          wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0, smem, lane, wv);
+        if ((!(TUNE & 4) && !(TUNE & 128)) || stage == 0)
+          wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, smem + G::PATCH, lane, wv);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         if (!(TUNE & 8) || stage == 0) __syncthreads();
         if (TUNE & 48) {
@@ -401,6 +404,8 @@ static int launch_wino(const float* X, int B, int H, int W, int CIN, const float
   if (tune == 12) PA_WINO_GO(48);
   if (tune == 28) PA_WINO_GO(112);
   if (tune == 60) PA_WINO_GO(240);
+  if (tune == 64) PA_WINO_GO(256);
+  if (tune == 128) PA_WINO_GO(512);
   PA_WINO_GO(0);
 #undef PA_WINO_GO
 }
