@@ -373,7 +373,10 @@ int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, co
     else pa::launch_conv<1, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
   } else if (stride == 2) {
     PA_REQUIRE(cout % 64 == 0, "pa_conv3x3: stride 2 needs cout %% 64 == 0");
-    if (Ho >= 16) pa::launch_conv<2, 4, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    static const int s2bn32 = getenv("PA_CONV_S2_BN32") ? atoi(getenv("PA_CONV_S2_BN32")) : 1;  // 2 WG/CU: +4-7 %
+    if (s2bn32 && Ho >= 16) pa::launch_conv<2, 4, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else if (s2bn32) pa::launch_conv<2, 2, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else if (Ho >= 16) pa::launch_conv<2, 4, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else pa::launch_conv<2, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
   } else {
     PA_REQUIRE(false, "pa_conv3x3: stride %d not supported", stride);

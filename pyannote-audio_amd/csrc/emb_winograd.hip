@@ -303,8 +303,26 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
     WinoTile nxt = cur;
     if (qn < total_tiles) nxt = wino_decode(qn, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
 
-    for (int c0 = 0; c0 < CIN; c0 += WCB, ++stage) {
-      if (MODE == 2) {
+    for (int c0 = 0; c0 < CIN; c0 += (MODE == 3 ? 2 * WCB : WCB), ++stage) {
+      if (MODE == 3) {
+        // 32-channel patch stage: both 16-channel halves of every pixel (one full 128-byte line in
+        // NHWC) are fetched back to back into two LDS planes; the U slab is staged per half.
+        float* p0 = smem;
+        float* p1 = smem + G::PATCH;
+        float* us = smem + 2 * G::PATCH;
+        __syncthreads();  // every wave is done reading the previous stage
+        wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0, p0, lane, wv);
+        wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0 + WCB, p1, lane, wv);
+        wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, us, lane, wv);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        wino_compute<TR, TCG, TUNE>(p0, us, acc, t, g, wr, wc);
+        __syncthreads();  // every wave is done reading the U slab
+        wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0 + WCB, us, lane, wv);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        wino_compute<TR, TCG, TUNE>(p1, us, acc, t, g, wr, wc);
+      } else if (MODE == 2) {
         float* us = smem + G::PATCH;
         // (all waves passed the barrier that ends the previous stage: the U slab is free)
         wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, us, lane, wv);
@@ -358,7 +376,8 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   using G = WinoGeom<TR, TCG>;
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
   constexpr int MODE = MODE_TUNE & 3;
-  const size_t lds = (size_t)(G::PATCH + G::USLAB) * (MODE == 1 ? 2 : 1) * sizeof(float);
+  const size_t lds = (size_t)(MODE == 3 ? 2 * G::PATCH + G::USLAB : (G::PATCH + G::USLAB) * (MODE == 1 ? 2 : 1)) *
+                     sizeof(float);
   static int resident = 0;
   if (!resident) {
     (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R, MODE_TUNE>,
@@ -387,6 +406,10 @@ static int launch_wino(const float* X, int B, int H, int W, int CIN, const float
   //             2 = 0 + split recycling of patch / U.  Measured on the full pipeline: 0 is the fastest
   //             (0.755 vs 0.733 audio-h/s for 2 and 0.627 for 1), hence the default.
   static const int mode = getenv("PA_WINO_MODE") ? atoi(getenv("PA_WINO_MODE")) : 0;
+  using G = WinoGeom<TR, TCG>;
+  if (mode == 3 && (2 * G::PATCH + G::USLAB) * sizeof(float) * 2 <= 160 * 1024 && CIN % 32 == 0)
+    return R != nullptr ? launch_wino_r<TR, TCG, true, 3>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
+                        : launch_wino_r<TR, TCG, false, 3>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
   if (mode == 2)
     return R != nullptr ? launch_wino_r<TR, TCG, true, 2>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
                         : launch_wino_r<TR, TCG, false, 2>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
