@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from .core import Annotation, Segment, SlidingWindow, SlidingWindowFeature, string_generator
+from .core import Annotation, SlidingWindow, SlidingWindowFeature, string_generator
 from .inference import Inference
 
 

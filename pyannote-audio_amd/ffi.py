@@ -6,7 +6,6 @@ is missing, every entry point raises."""
 from __future__ import annotations
 
 import ctypes as C
-import os
 from pathlib import Path
 
 import torch

@@ -9,7 +9,6 @@ model that has not been moved to a GPU raises: there is no CPU compute path in t
 from __future__ import annotations
 
 import contextlib
-import io
 import os
 import pickle
 import sys
@@ -20,7 +19,6 @@ from functools import cached_property
 from pathlib import Path
 from typing import List, Optional, Text, Tuple
 
-import numpy as np
 import scipy.special
 import torch
 

@@ -15,7 +15,7 @@ import textwrap
 import time
 import warnings
 from dataclasses import dataclass
-from typing import Any, Callable, Mapping, Optional
+from typing import Any, Callable, Optional
 
 import numpy as np
 import torch

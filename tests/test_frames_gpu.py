@@ -2,7 +2,6 @@
 speaker_count / reconstruct / to_diarization / filter statistics: bit-exact (integer work)."""
 import numpy as np
 import pytest
-import torch
 
 pytestmark = pytest.mark.gpu
 

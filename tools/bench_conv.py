@@ -1,6 +1,6 @@
 """Per-shape timing of pa_conv3x3 on the ResNet34 layer shapes (development aid; HIP events through
 the library profiler).  usage: python tools/bench_conv.py [B] [reps]"""
-import os, sys, json
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pyannote_audio_amd.ffi as ffi

@@ -6,7 +6,6 @@ from scipy.spatial.distance import pdist
 from pyannote_audio_amd import distance
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-import sys as _s
 emb_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_train_emb.npy")
 if os.path.exists(emb_file):
     X = np.load(emb_file); X = X / np.linalg.norm(X, axis=1, keepdims=True)
