@@ -178,6 +178,8 @@ def main():
     import pyannote_audio_amd.ffi as ffi
     ffi.require_gpu()
 
+    # host threads for the (untimed) checkpoint synthesis: do not oversubscribe the node at N > 1
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
     workdir = tempfile.mkdtemp(prefix=f"pa_bench_r{rank}_")
     seg_o, emb_o = build_checkpoints(workdir)
     pipeline = pa.Pipeline.from_pretrained(workdir)
