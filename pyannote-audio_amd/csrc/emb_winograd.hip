@@ -54,7 +54,8 @@ struct WinoTile {
 
 // LDS-DMA of one stage (16 input channels from c0) of tile q:
 // piece k fills LDS rows 16k .. 16k+15; lane l -> row 16k + (l>>2), physical slot l&3.
-template <int TR, int TCG>
+// BLK (measurement aid for the round-2 layout study): read X as channel-blocked [c/16][h][w][16]
+template <int TR, int TCG, bool BLK = false>
 __device__ __forceinline__ void wino_issue_patch(const float* __restrict__ X, int H, int W, int CIN,
                                                  const WinoTile& q, int c0, float* patch, int lane,
                                                  int wv) {
@@ -72,10 +73,10 @@ __device__ __forceinline__ void wino_issue_patch(const float* __restrict__ X, in
     const int pr = row / G::PWH, idx = row % G::PWH;         // pr = py*2 + parity
     const int py = pr >> 1, px = 2 * idx + (pr & 1);
     const int iy = q.y0 - 1 + py, ix = q.x0 - 1 + px;
-    const int off = (row < G::PROWS && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                        ? ((iy * W + ix) * CIN + 4 * gq) * 4
-                        : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(patch + 256 * k), 16, off, c0 * 4, 0, 0);
+    const bool inb = row < G::PROWS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int off = !inb ? OOB : BLK ? ((iy * W + ix) * 16 + 4 * gq) * 4 : ((iy * W + ix) * CIN + 4 * gq) * 4;
+    const int soff = BLK ? (c0 / 16) * H * W * 64 : c0 * 4;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(patch + 256 * k), 16, off, soff, 0, 0);
   }
 }
 
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
         if (!(TUNE & 8) || stage == 0) __syncthreads();  // every wave is done reading the previous stage
         // (64 = patch staged only once, 128 = U slab staged only once)
         if ((!(TUNE & 4) && !(TUNE & 64)) || stage == 0)
-          wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0, smem, lane, wv);
+          wino_issue_patch<TR, TCG, (TUNE & 256) != 0>(X, H, W, CIN, cur, c0, smem, lane, wv);
         if ((!(TUNE & 4) && !(TUNE & 128)) || stage == 0)
           wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, smem + G::PATCH, lane, wv);
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -429,6 +430,7 @@ static int launch_wino(const float* X, int B, int H, int W, int CIN, const float
   if (tune == 60) PA_WINO_GO(240);
   if (tune == 64) PA_WINO_GO(256);
   if (tune == 128) PA_WINO_GO(512);
+  if (tune == 256) PA_WINO_GO(1024);
   PA_WINO_GO(0);
 #undef PA_WINO_GO
 }
