@@ -80,6 +80,53 @@ __device__ __forceinline__ void wino_issue_patch(const float* __restrict__ X, in
   }
 }
 
+// Patch DMA with the per-lane address arithmetic hoisted out of the stage loop: for every piece this
+// wave issues, `prel` = byte offset of the lane's (patch row, quad) relative to the patch origin and
+// `pyx` = (patch y << 16) | patch x are computed ONCE per kernel (they contain the divisions by the
+// patch width); a stage only adds the tile origin and checks the image bounds (2 unsigned compares).
+template <int TR, int TCG>
+struct WinoPatchLanes {
+  static constexpr int NPP = (WinoGeom<TR, TCG>::PINSTR + WinoGeom<TR, TCG>::NWV - 1) / WinoGeom<TR, TCG>::NWV;
+  int prel[NPP], pyx[NPP];
+};
+
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_patch_lanes(WinoPatchLanes<TR, TCG>& pl, int W, int CIN, int lane,
+                                                 int swv) {
+  using G = WinoGeom<TR, TCG>;
+#pragma unroll
+  for (int i = 0; i < WinoPatchLanes<TR, TCG>::NPP; ++i) {
+    const int k = swv + G::NWV * i;
+    const int row = 16 * k + (lane >> 2);
+    const int gq = ((lane & 3) - 2 * ((row >> 2) & 1)) & 3;  // logical quad stored in this slot
+    const int pr = row / G::PWH, idx = row % G::PWH;         // pr = py*2 + parity
+    const int py = pr >> 1, px = 2 * idx + (pr & 1);
+    const bool real = k < G::PINSTR && row < G::PROWS;
+    pl.prel[i] = ((py * W + px) * CIN + 4 * gq) * 4;
+    pl.pyx[i] = real ? ((py << 16) | px) : 0x7fff7fff;       // (never inside an image)
+  }
+}
+
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_issue_patch_fast(const float* __restrict__ X, int H, int W, int CIN,
+                                                      const WinoTile& q, int c0, float* patch,
+                                                      const int* prel, const int* pyx, int swv) {
+  using G = WinoGeom<TR, TCG>;
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+  const int tile_rel = ((q.y0 - 1) * W + (q.x0 - 1)) * CIN * 4;
+#pragma unroll
+  for (int i = 0; i < WinoPatchLanes<TR, TCG>::NPP; ++i) {
+    const int k = swv + G::NWV * i;
+    if (k >= G::PINSTR) break;  // wave-uniform
+    const int iy = q.y0 - 1 + (pyx[i] >> 16), ix = q.x0 - 1 + (pyx[i] & 0xffff);
+    const bool inb = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_ptr_t)(patch + 256 * k), 16,
+                                             inb ? prel[i] + tile_rel : OOB, c0 * 4, 0, 0);
+  }
+}
+
 template <int TR, int TCG>
 __device__ __forceinline__ void wino_issue_u(const float* __restrict__ U, int CIN, int COUT,
                                              const WinoTile& q, int c0, float* uslab, int lane, int wv) {
@@ -284,6 +331,9 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
   if (q >= total_tiles) return;
   WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
   int stage = 0;
+  const int swv = __builtin_amdgcn_readfirstlane(wv);
+  WinoPatchLanes<TR, TCG> plan;
+  if constexpr (MODE == 0) wino_patch_lanes<TR, TCG>(plan, W, CIN, lane, swv);
   f32x4 dbg_v[4][4];  // (measurement aids only)
   if (TUNE & 48)
 #pragma unroll
@@ -352,8 +402,12 @@ __global__ __launch_bounds__(64 * TR * TCG, ((MODE_TUNE & 3) == 1 && TR * TCG ==
         // 16 = input transform only once, 32 = B fragments read only once
         if (!(TUNE & 8) || stage == 0) __syncthreads();  // every wave is done reading the previous stage
         // (64 = patch staged only once, 128 = U slab staged only once)
-        if ((!(TUNE & 4) && !(TUNE & 64)) || stage == 0)
-          wino_issue_patch<TR, TCG, (TUNE & 256) != 0>(X, H, W, CIN, cur, c0, smem, lane, wv);
+        if ((!(TUNE & 4) && !(TUNE & 64)) || stage == 0) {
+          if constexpr (MODE != 0 || (TUNE & 256) != 0)
+            wino_issue_patch<TR, TCG, (TUNE & 256) != 0>(X, H, W, CIN, cur, c0, smem, lane, wv);
+          else
+            wino_issue_patch_fast<TR, TCG>(X, H, W, CIN, cur, c0, smem, plan.prel, plan.pyx, swv);
+        }
         if ((!(TUNE & 4) && !(TUNE & 128)) || stage == 0)
           wino_issue_u<TR, TCG>(U, CIN, COUT, cur, c0, smem + G::PATCH, lane, wv);
         __builtin_amdgcn_s_waitcnt(0x0F70);
