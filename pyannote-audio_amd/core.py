@@ -224,7 +224,20 @@ if not HAVE_PYANNOTE_CORE:
                 starts, ends = starts[idx], ends[idx]
                 tracks = [tracks[i] for i in idx]
                 labels = [labels[i] for i in idx]
-            out._cols = (starts, ends, list(tracks), list(labels))
+            tracks, labels = list(tracks), list(labels)
+            # `annotation[segment, track] = label` is last-write-wins per (segment, track): keep only
+            # the last row of every duplicated key so that the columnar answers (labels(), len(),
+            # rename_labels()) equal those of the incrementally built container.
+            last = {}
+            for i, key in enumerate(zip(starts.tolist(), ends.tolist(), tracks)):
+                last[key] = i
+            if len(last) < len(tracks):
+                idx = np.fromiter(last.values(), dtype=np.int64, count=len(last))
+                idx.sort()
+                starts, ends = starts[idx], ends[idx]
+                tracks = [tracks[i] for i in idx]
+                labels = [labels[i] for i in idx]
+            out._cols = (starts, ends, tracks, labels)
             return out
 
         @property

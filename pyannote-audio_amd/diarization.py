@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from .core import Annotation, SlidingWindow, SlidingWindowFeature, string_generator
+from .core import Annotation, Segment, SlidingWindow, SlidingWindowFeature, string_generator
 from .inference import Inference
 
 
@@ -110,11 +110,17 @@ class Binarize:
             col_end.append(timestamps[downs[:m]] + self.pad_offset)
             col_track += [track] * m
             col_label += [label] * m
-        if col_start:
+        if col_start and hasattr(Annotation, "from_columns"):
             active = Annotation.from_columns(np.concatenate(col_start), np.concatenate(col_end),
                                              col_track, col_label)
         else:
+            # the real pyannote.core.Annotation (re-exported by core.py when it is importable) has no
+            # columnar constructor: insert the rows the way utils/signal.py:283-305 does
             active = Annotation()
+            if col_start:
+                for a, b, t, l in zip(np.concatenate(col_start).tolist(),
+                                      np.concatenate(col_end).tolist(), col_track, col_label):
+                    active[Segment(a, b), t] = l
         if self.pad_offset > 0.0 or self.pad_onset > 0.0 or self.min_duration_off > 0.0:
             active = active.support(collar=self.min_duration_off)
         if self.min_duration_on > 0:

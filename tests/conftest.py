@@ -39,6 +39,21 @@ def report(name, got, want, log=None):
     return diff.max().item()
 
 
+def north_star_ratio(name, got, want, rtol=1e-4, atol=1e-5):
+    """BASELINE.json north_star / SURVEY.md section 8d float tolerance for segmentation log-probs and
+    embeddings: |got - want| <= atol + rtol * |want| element-wise (rtol 1e-4, atol 1e-5).  Returns
+    max |d| / (atol + rtol |want|) (<= 1 passes) and logs it next to the max-abs/max-rel summary."""
+    import torch
+    got = torch.as_tensor(got).detach().double().cpu()
+    want = torch.as_tensor(want).detach().double().cpu()
+    report(name, got, want)
+    ratio = ((got - want).abs() / (atol + rtol * want.abs())).max().item()
+    with open(os.path.join(ROOT, "gpurun_out", "parity.log"), "a") as fp:
+        fp.write(f"{name}: north-star ratio (rtol={rtol:g}, atol={atol:g}) = {ratio:.3f}\n")
+    print(f"{name}: north-star ratio = {ratio:.3f}")
+    return ratio
+
+
 PYANNET_HPARAMS = {
     "sincnet": {"stride": 10, "sample_rate": 16000},
     "lstm": {"hidden_size": 128, "num_layers": 4, "bidirectional": True, "monolithic": True,

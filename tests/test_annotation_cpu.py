@@ -34,6 +34,43 @@ def test_columnar_equals_incremental(rows):
     assert list(col2.itertracks(yield_label=True)) == list(inc.itertracks(yield_label=True))
 
 
+def test_columnar_duplicate_keys_last_write_wins():
+    """the hypothesis counter-example of round 1: same (segment, track), different labels"""
+    rows = [(0.0, 1.0, "A", 0), (0.0, 1.0, "A", 1)]
+    col = Annotation.from_columns(*zip(*rows))
+    inc = Annotation()
+    for a, b, t, l in rows:
+        inc[Segment(a, b), t] = l
+    assert col.labels() == inc.labels() == [1]
+    assert len(col) == len(inc) == 1
+    assert col == inc
+
+
+def test_binarize_with_pyannote_core_style_annotation(monkeypatch):
+    """When the real pyannote.core is importable core.py re-exports ITS Annotation, which has no
+    `from_columns`: Binarize must fall back to item assignment (utils/signal.py:283-305)."""
+    import pyannote_audio_amd.diarization as dz
+
+    class PlainAnnotation:
+        def __init__(self, uri=None, modality=None):
+            self.rows = {}
+
+        def __setitem__(self, key, label):
+            segment, track = key
+            if segment:
+                self.rows[(segment.start, segment.end, track)] = label
+
+    d = np.zeros((50, 2), np.float32)
+    d[3:10, 0] = 1
+    d[20:50, 1] = 1
+    frames = SlidingWindow(start=0.0, duration=0.0619375, step=0.016875)
+    want = to_annotation(SlidingWindowFeature(d, frames))
+    monkeypatch.setattr(dz, "Annotation", PlainAnnotation)
+    got = dz.to_annotation(SlidingWindowFeature(d, frames))
+    assert sorted(got.rows.items()) == sorted(
+        ((s.start, s.end, t), l) for s, t, l in want.itertracks(yield_label=True))
+
+
 @settings(max_examples=40, deadline=None)
 @given(st.integers(1, 400), st.integers(1, 4), st.integers(0, 2 ** 31 - 1))
 def test_binarize_matches_oracle(num_frames, K, seed):

@@ -1,0 +1,92 @@
+"""BASELINE.json configs[0]: `Inference` of the segmentation model over the reference's own 30 s
+fixture (src/pyannote/audio/sample/sample.wav, copied to tests/golden/sample.wav; 16 kHz mono PCM16;
+sample.rttm = 2 speakers, 10 turns), with the structural checks of the reference's
+tests/inference_test.py:59-63 (step > duration -> ValueError) and :94-97 (skip_aggregation -> 3-D
+SlidingWindowFeature), then the same file through the full pipeline, HIP path vs the oracle.
+Weights are the seeded synthetic checkpoints (no pretrained weights exist offline), so sample.rttm
+pins the file format only, not the diarization."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import report
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+SAMPLE = os.path.join(GOLDEN, "sample.wav")
+
+
+def test_sample_fixture_geometry_cpu():
+    """21 chunks of 10 s every 1 s, no orphan chunk; RTTM fixture parses as the wire format."""
+    from pyannote_audio_amd.audio import Audio
+    from pyannote_audio_amd.inference import Inference
+    wav, sr = Audio(16000, mono="downmix")(SAMPLE)
+    assert sr == 16000 and tuple(wav.shape) == (1, 480000) and wav.dtype == torch.float32
+    assert Inference.num_chunks(480000, 160000, 16000) == (21, False)
+    rows = [l.split() for l in open(os.path.join(GOLDEN, "sample.rttm")) if l.strip()]
+    assert len(rows) == 10 and {r[0] for r in rows} == {"SPEAKER"} and {r[1] for r in rows} == {"sample"}
+    assert len({r[7] for r in rows}) == 2
+
+
+def test_step_longer_than_duration_raises_cpu(synthetic_models, tmp_path):
+    """tests/inference_test.py:59-63"""
+    import pyannote_audio_amd as pa
+    from conftest import write_pipeline_dir
+    write_pipeline_dir(tmp_path, *synthetic_models)
+    model = pa.Model.from_pretrained(os.path.join(str(tmp_path), "segmentation"))
+    with pytest.raises(ValueError):
+        pa.Inference(model, duration=model.specifications.duration,
+                     step=model.specifications.duration + 1)
+
+
+@pytest.mark.gpu
+def test_inference_on_sample_wav(pipeline_dir, synthetic_models, gpu_device):
+    """configs[0] on the GPU path: SlidingWindowFeature (21, 589, 3), equal to the oracle's
+    `Inference.slide` + `Powerset.to_multilabel(hard)`; log-probs within the float tolerance."""
+    import pyannote_audio_amd as pa
+    from oracle import pipeline as op
+    seg_o, _ = synthetic_models
+    model = pa.Model.from_pretrained(os.path.join(pipeline_dir, "segmentation")).to(gpu_device)
+    inference = pa.Inference(model, skip_aggregation=True)
+    swf = inference(SAMPLE)
+    assert isinstance(swf, pa.SlidingWindowFeature)
+    assert swf.data.ndim == 3 and swf.data.shape == (21, 589, 3)          # inference_test.py:94-97
+    assert (swf.sliding_window.duration, swf.sliding_window.step) == (10.0, 1.0)
+    wav, sr = pa.Audio(16000, mono="downmix")(SAMPLE)
+    ref = op.slide(seg_o, wav, sr, 10.0, 1.0, 32)
+    assert ref.shape == (21, 589, 3)
+    chunks = wav.unfold(1, 160000, 16000).permute(1, 0, 2)
+    with torch.inference_mode():
+        ref_logp = seg_o(chunks)
+    got_logp = model(chunks.to(gpu_device)).cpu()
+    err = report("config1_sample_logp", got_logp, ref_logp)
+    assert err <= 1e-4 * max(1.0, ref_logp.abs().max().item())
+    top2 = torch.topk(ref_logp, 2, dim=-1).values
+    safe = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+    mism = (swf.data != ref).any(axis=-1)
+    assert not (mism & safe).any()
+    with open("gpurun_out/parity.log", "a") as fp:
+        fp.write(f"config1_sample: hard-decision mismatches {int(mism.sum())} of {mism.size} frames "
+                 f"(all inside the 1e-3 top-2 gap)\n")
+
+
+@pytest.mark.gpu
+def test_full_pipeline_on_sample_wav(pipeline_dir, synthetic_models, gpu_device):
+    """path-on-disk front door -> DiarizeOutput, identical turns to the oracle on real speech"""
+    import pyannote_audio_amd as pa
+    from oracle.pipeline import diarize
+    seg_o, emb_o = synthetic_models
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir).to(gpu_device)
+    out = pipeline(SAMPLE)
+    wav, _ = pa.Audio(16000, mono="downmix")(SAMPLE)
+    ref = diarize(seg_o, emb_o, wav, exclude_overlap=True)
+    got = [(s.start, s.end, l) for s, _, l in out.speaker_diarization.itertracks(yield_label=True)]
+    assert got == ref.diarization
+    gotx = [(s.start, s.end, l)
+            for s, _, l in out.exclusive_speaker_diarization.itertracks(yield_label=True)]
+    assert gotx == ref.exclusive_diarization
+    assert out.speaker_diarization.uri == "sample"
+    for line in out.speaker_diarization.to_rttm().splitlines():
+        f = line.split()
+        assert len(f) == 10 and f[0] == "SPEAKER" and f[1] == "sample" and f[2] == "1"

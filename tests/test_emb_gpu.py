@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import report
+from conftest import north_star_ratio, report
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +52,17 @@ def test_fbank(emb, gpu_device):
     torch.cuda.synchronize()
     assert out.shape == ref.shape
     e = report("fbank_centered", out, ref)
-    assert e < 2e-3  # log-domain; low-energy bins carry FFT round-off of the whole frame
+    # (a) energy domain, relative to max(value, 1e-3 x peak): the float tolerance of the contract
+    # (b) log domain: bins 1e-4 of the peak carry the FFT round-off of the whole frame in BOTH
+    #     float32 implementations (the float32 oracle itself is 5e-3 away from a float64 evaluation
+    #     there, tests/test_oracle_fbank_pin.py), so the log-domain bound is loose by construction
+    e_ref = torch.exp(ref.double())          # centring is a common factor in the energy domain
+    e_got = torch.exp(out.cpu().double())
+    rel = ((e_got - e_ref).abs() / torch.maximum(e_ref, 1e-3 * e_ref.amax(dim=(1, 2), keepdim=True))).max().item()
+    with open("gpurun_out/parity.log", "a") as fp:
+        fp.write(f"fbank_centered: energy-domain rel err = {rel:.3e}\n")
+    assert rel < 1e-4
+    assert e < 2e-3
 
 
 def test_conv3x3_configs(gpu_device):
@@ -142,10 +152,9 @@ def test_emb_forward_end_to_end(emb, gpu_device, B, N):
     out = eng.forward(x.to(gpu_device), masks.to(gpu_device))
     out1 = eng.forward(x[:2].to(gpu_device))
     torch.cuda.synchronize()
-    e = report(f"emb_B{B}_N{N}", out, ref)
-    assert torch.allclose(out.cpu(), ref, rtol=1e-3, atol=2e-4 * ref.abs().max().item())
-    report(f"emb_unweighted_N{N}", out1, ref1)
-    assert torch.allclose(out1.cpu(), ref1, rtol=1e-3, atol=2e-4 * ref1.abs().max().item())
+    # north_star tolerance for embeddings: rtol 1e-4, atol 1e-5
+    assert north_star_ratio(f"emb_B{B}_N{N}", out, ref) <= 1.0
+    assert north_star_ratio(f"emb_unweighted_N{N}", out1, ref1) <= 1.0
 
 
 def test_conv3x3_winograd(gpu_device):

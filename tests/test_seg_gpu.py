@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import report
+from conftest import north_star_ratio, report
 
 pytestmark = pytest.mark.gpu
 
@@ -162,8 +162,8 @@ def test_seg_forward_end_to_end(seg, gpu_device, B, N, stride):
         ref = model(chunks)
     logp, ml = eng.forward_strided(wav.to(gpu_device), stride, B, N)
     torch.cuda.synchronize()
-    e = report(f"seg_logp_B{B}_N{N}", logp, ref)
-    assert torch.allclose(logp.cpu(), ref, rtol=1e-4, atol=2e-4)
+    # north_star tolerance for segmentation log-probs: rtol 1e-4, atol 1e-5
+    assert north_star_ratio(f"seg_logp_B{B}_N{N}", logp, ref) <= 1.0
     # hard powerset decisions identical except where the top-2 gap is below tolerance
     top2 = ref.topk(2, dim=-1).values
     safe = (top2[..., 0] - top2[..., 1]) > 1e-3
@@ -172,4 +172,4 @@ def test_seg_forward_end_to_end(seg, gpu_device, B, N, stride):
     assert torch.equal(ml.cpu()[safe], ref_ml[safe])
     # reference Model.forward contract: (B,1,N) in -> (B,F,K) out
     out = eng.forward(chunks[:2].to(gpu_device))
-    assert torch.allclose(out.cpu(), ref[:2], rtol=1e-4, atol=2e-4)
+    assert north_star_ratio(f"seg_forward_contract_N{N}", out, ref[:2]) <= 1.0
