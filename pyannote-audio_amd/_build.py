@@ -47,6 +47,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         for line in src.read_text().splitlines():
             if line.startswith("// hipcc-flags:"):
                 extra += line.split(":", 1)[1].split()
+        extra += os.environ.get("PA_EXTRA_FLAGS", "").split()   # development aids only (e.g. -DPA_WINO_DEBUG)
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *extra,
                "-I", str(PKG_DIR.parent / "include"), "-c", str(src), "-o", str(obj)]
         if verbose:

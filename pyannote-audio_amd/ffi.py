@@ -55,6 +55,10 @@ class LibraryNotBuilt(RuntimeError):
 
 
 def lib_path() -> Path:
+    # PA_LIB: development aid (e.g. an instrumented build next to the product library)
+    import os
+    if os.environ.get("PA_LIB"):
+        return Path(os.environ["PA_LIB"])
     return Path(__file__).resolve().parent / "libpyannote_amd.so"
 
 

@@ -203,6 +203,23 @@ def winograd_weights(cw: torch.Tensor) -> torch.Tensor:
     return U.reshape(16, cw.shape[0], cw.shape[1]).float().contiguous()
 
 
+def winograd_pack(U: torch.Tensor) -> torch.Tensor:
+    """[16][cout][cin] -> the kernel's staging image [cout/32][cin/16][512 rows][4 slots][4]: one
+    CONTIGUOUS 32-KB slab per (32-cout slice, 16-cin stage) so that its LDS-DMA is a linear full-line
+    stream (the strided [16][cout][cin] form reads 64-byte pieces 4*cin bytes apart: at cin = 256 they
+    fall on a quarter of the L2 channels).  Row r = 32 xi + n holds channel quad g at physical slot
+    (g + 2 ((r >> 2) & 1)) & 3 -- the bank-conflict-free LDS layout of csrc/emb_winograd.hip, applied on
+    the host so that the DMA needs no per-lane address arithmetic."""
+    _, cout, cin = U.shape
+    assert cout % 32 == 0 and cin % 16 == 0
+    A = U.reshape(16, cout // 32, 32, cin // 16, 4, 4).permute(1, 3, 0, 2, 4, 5)
+    A = A.reshape(cout // 32, cin // 16, 512, 4, 4)
+    r = torch.arange(512)
+    quad_of_slot = (torch.arange(4)[None, :] - 2 * ((r >> 2) & 1)[:, None]) & 3      # (512, 4)
+    idx = quad_of_slot.view(1, 1, 512, 4, 1).expand(A.shape[0], A.shape[1], 512, 4, 4)
+    return torch.gather(A, 3, idx).contiguous()
+
+
 def _fold_bn(sd: dict, prefix: str, eps: float = 1e-5):
     scale = sd[prefix + ".weight"] / torch.sqrt(sd[prefix + ".running_var"] + eps)
     shift = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale
@@ -262,7 +279,7 @@ class EmbeddingPack:
                     getattr(w, f"blk_shift{j}")[blk] = self._up(sh).value
                     stride = 2 if (j == 1 and i == 0 and l > 0) else 1
                     if winograd and stride == 1:
-                        getattr(w, f"blk_u{j}")[blk] = self._up(winograd_weights(cw)).value
+                        getattr(w, f"blk_u{j}")[blk] = self._up(winograd_pack(winograd_weights(cw))).value
                 if f"{pre}.shortcut.0.weight" in sd:
                     sc, sh = _fold_bn(sd, f"{pre}.shortcut.1")
                     cw = sd[f"{pre}.shortcut.0.weight"][:, :, 0, 0] * sc.view(-1, 1)

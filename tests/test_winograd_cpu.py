@@ -48,3 +48,17 @@ def test_lds_swizzle_is_conflict_free():
                 row = base + t
                 slots.add((4 * row + ((g + 2 * ((row >> 2) & 1)) & 3)) % 16)
             assert len(slots) == 16
+
+
+def test_winograd_pack_is_the_lds_image():
+    """weights.winograd_pack: slab (cout slice o, cin stage c) row r = 32 xi + n, physical slot
+    (g + 2 ((r >> 2) & 1)) & 3 holds U[xi][32 o + n][16 c + 4 g : 16 c + 4 g + 4]."""
+    from pyannote_audio_amd.weights import winograd_pack
+    cout, cin = 64, 48
+    U = torch.arange(16 * cout * cin, dtype=torch.float32).reshape(16, cout, cin)
+    P = winograd_pack(U)
+    assert P.shape == (cout // 32, cin // 16, 512, 4, 4) and P.is_contiguous()
+    for (o, c, xi, n, g) in [(0, 0, 0, 0, 0), (1, 2, 15, 31, 3), (1, 1, 7, 4, 1), (0, 2, 3, 5, 2), (1, 0, 9, 12, 0)]:
+        r = 32 * xi + n
+        slot = (g + 2 * ((r >> 2) & 1)) & 3
+        assert torch.equal(P[o, c, r, slot], U[xi, 32 * o + n, 16 * c + 4 * g:16 * c + 4 * g + 4])

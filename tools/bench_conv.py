@@ -21,9 +21,9 @@ for (H, W, ci, co, s, res) in shapes:
     sh = torch.randn(co, device=dev)
     R = torch.randn(B, Ho, Wo, co, device=dev) if res else None
     Y = torch.empty(B, Ho, Wo, co, device=dev)
-    from pyannote_audio_amd.weights import winograd_weights
+    from pyannote_audio_amd.weights import winograd_pack, winograd_weights
     wino = os.environ.get("WINO", "0") == "1" and s == 1
-    Ug = winograd_weights(Wg.permute(1, 2, 0).reshape(co, ci, 3, 3).cpu()).to(dev) if wino else None
+    Ug = winograd_pack(winograd_weights(Wg.permute(1, 2, 0).reshape(co, ci, 3, 3).cpu())).to(dev) if wino else None
     def run():
         if wino:
             ffi.check(lib.pa_conv3x3_wino(ffi.ptr(X), B, H, W, ci, ffi.ptr(Ug), ffi.ptr(sh), ffi.ptr(R), ffi.ptr(Y),
