@@ -42,6 +42,8 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec
 MFMA_KERNELS = {"k_conv3x3", "k_conv3x3_wino", "k_gemm_tn", "k_lstm_rec", "k_sinc_fir_pool", "k_conv5_pool"}
 # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and (cin, cout) pair instead of 36
 EXECUTED_FLOP_FRACTION = {"k_conv3x3_wino": 16.0 / 36.0}
+# bare f32-MFMA stream measured on this chip with random operands (tools/probes/pingpong_probe.py)
+SUSTAINED_MFMA_F32_TFLOPS = 132.8
 
 
 def build_checkpoints(workdir: str):
@@ -151,14 +153,138 @@ def cpu_baseline(seg_o, emb_o, seconds: float):
             f"{dt:.1f} s wall", "stages_s": {k: round(v, 3) for k, v in out.timings.items()}}
 
 
+def load_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; summarised by
+    tools/pmc_traffic.py).  PMC counters cannot be read from inside this process, so the figure is a
+    STATIC one and says which file / commit it comes from."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fp:
+                d = json.load(fp)
+        except OSError:
+            continue
+        if kernel in d:
+            src = f"profiles/{name}" + (f"@{d['_commit']}" if "_commit" in d else "")
+            return d[kernel].get("hbm_bytes_per_launch"), src
+    return None, None
+
+
+def roofline_entry(name: str, r: dict) -> dict:
+    """`roofline` object for one kernel from the library profiler's record (HIP events on the launch
+    stream): `achieved` is what the bounding unit really executed -- for the Winograd kernel the
+    matrix pipe issues 16/36 of the direct convolution's multiplies, so `achieved` counts those and
+    `frac` <= 1; the reference operation's (direct-convolution) rate is reported separately."""
+    launches = max(r["launches"], 1)
+    avg_ms = r["ms"] / launches
+    traffic, src = load_traffic(name)
+    if name in MFMA_KERNELS:
+        algorithmic = r["flops"] / r["ms"] / 1e9
+        executed = algorithmic * EXECUTED_FLOP_FRACTION.get(name, 1.0)
+        roof = {"kernel": name, "bound": "mfma", "achieved": round(executed, 2),
+                "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
+                "algorithmic": {"tflops": round(algorithmic, 2),
+                                "gflop_per_launch": round(r["flops"] / launches / 1e9, 3),
+                                "note": "flops of the reference operation (direct 3x3 convolution)"},
+                "executed_gflop_per_launch": round(
+                    r["flops"] * EXECUTED_FLOP_FRACTION.get(name, 1.0) / launches / 1e9, 3),
+                # bare v_mfma_f32_16x16x4_f32 stream on this chip: 132.8 TFLOP/s on random data (the
+                # chip clocks 2.07 GHz under that load), 149 on zeros (profiles/r2_mfma_probe.txt)
+                "sustained_mfma_tflops": SUSTAINED_MFMA_F32_TFLOPS,
+                "frac_of_sustained": round(executed / SUSTAINED_MFMA_F32_TFLOPS, 4)}
+    else:
+        ach = r["bytes"] / r["ms"] / 1e6
+        roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4)}
+    roof.update({"traffic": traffic, "traffic_source": src,
+                 "algorithmic_bytes_per_launch": round(r["bytes"] / launches),
+                 "launches": r["launches"], "avg_launch_ms": round(avg_ms, 4)})
+    return roof
+
+
+def bench_stage(args, pipeline, device, rank):
+    """BASELINE.json configs[1] / configs[2]: one model stage alone, inputs resident in HBM.
+    A step = one pass over the whole synthetic input."""
+    import pyannote_audio_amd.ffi as ffi
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    if args.config == "seg5s":
+        wav = synth_hour(args.hours, seed=rank, device=device).view(-1)
+        window, stride = 80000, 8000
+        num = (wav.numel() - window) // stride + 1
+        engine = pipeline._segmentation.model.engine
+        per_unit_gflop = 1.313      # SURVEY.md section 8a: PyanNet (L = 4) on one 5 s chunk
+        workload = (f"PyanNet sliding window 5 s / 0.5 s over {args.hours:g} h of 16 kHz audio "
+                    f"({num} chunks, one launch group)")
+        metric, unit, units_per_step = "segmentation chunks/s (5 s chunks)", "chunks/s", num
+
+        def step():
+            engine.forward_strided(wav, stride, num, window, want_logp=True, want_multilabel=True)
+    else:
+        num, window = 10000, 48000
+        wav = (0.1 * torch.randn(num * window, device=device, generator=g)).clamp_(-1, 1)
+        Fm = 173                     # segmentation frames of a 3 s chunk
+        masks = (torch.rand((num, 1, Fm), device=device, generator=g) < 0.7).float()
+        engine = pipeline._embedding.model_.engine
+        per_unit_gflop = 13.575      # SURVEY.md section 8a: ResNet34 on one 3 s item
+        workload = "WeSpeaker ResNet34 embeddings of 10 000 x 3 s segments, Bernoulli(0.7) masks"
+        metric, unit, units_per_step = "embedding segments/s (3 s segments)", "segments/s", num
+
+        def step():
+            engine.forward_strided(wav, window, num, window, masks)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ffi.prof_enable(True)
+    step()
+    torch.cuda.synchronize()
+    prof = ffi.prof_report()
+    ffi.prof_enable(False)
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    rate = units_per_step * args.steps / elapsed
+    stage_tflops = rate * per_unit_gflop / 1e3
+    line = {"metric": metric, "value": round(rate, 1), "unit": unit, "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": workload},
+            "audio_hours_per_s": round(rate * (window / 16000.0) / 3600.0 *
+                                       (0.1 if args.config == "seg5s" else 1.0), 4),
+            "stage_algorithmic": {"tflops": round(stage_tflops, 2),
+                                  "frac_of_f32_mfma_peak": round(stage_tflops / PEAK_MFMA_F32_TFLOPS, 4),
+                                  "gflop_per_unit": per_unit_gflop},
+            "roofline": roofline_entry(dom, prof[dom]),
+            "kernels": {k: {"launches": r["launches"], "ms": round(r["ms"], 3),
+                            "tflops": round(r["flops"] / r["ms"] / 1e9, 2) if r["ms"] > 0 else None,
+                            "gbs": round(r["bytes"] / r["ms"] / 1e6, 1) if r["ms"] > 0 else None}
+                        for k, r in prof.items()},
+            "cpu_baseline": None}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours", type=float, default=1.0, help="audio hours per GPU and step")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["pipeline", "seg5s", "emb3s"], default="pipeline",
+                    help="pipeline = BASELINE.json configs[3] (the headline metric; configs[4] at N > 1); "
+                         "seg5s = configs[1] (PyanNet 5 s / 0.5 s over 1 h); emb3s = configs[2] (ResNet34 on "
+                         "10 000 x 3 s segments)")
+    ap.add_argument("--joint", action="store_true",
+                    help="N > 1: ONE joint clustering over the files of all ranks (configs[4] as written) "
+                         "instead of per-file clustering")
+    ap.add_argument("--sequential", action="store_true",
+                    help="one pipeline(file) call per step instead of the pipelined apply_batch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,40 +311,66 @@ def main():
     pipeline = pa.Pipeline.from_pretrained(workdir)
     pipeline.to(device)
 
+    if args.config != "pipeline":
+        return bench_stage(args, pipeline, device, rank)
+
     wav = synth_hour(args.hours, seed=rank, device=device)      # resident in HBM before timing
     file = {"waveform": wav, "sample_rate": 16000, "uri": f"synthetic_{rank}"}
     timer = StageTimer()
+    shard = None
+    if exchange:
+        from pyannote_audio_amd import parallel
+        shard = parallel.shard_from_env()
 
-    def step():
-        timer.start()
-        out = pipeline(file, hook=timer)
-        if exchange:
-            # exchange step of configs[4]: per-chunk hard segmentations + embeddings of every file
-            payload = pipeline.last_exchange_payload(device)
-            gathered = torch.empty((world,) + tuple(payload.shape), dtype=payload.dtype, device=device)
-            dist.all_gather_into_tensor(gathered, payload)
-        return out
+    def exchange_records():
+        # exchange step of configs[4]: per-chunk hard segmentations + embeddings of every rank's file,
+        # device buffers over RCCL (the joint mode does this inside apply_batch instead)
+        payload = pipeline.last_exchange_payload(device)
+        parallel.all_gather_records(payload, shard)
+
+    def run(num_files: int, tag: str):
+        """`num_files` steps = `num_files` one-hour files through the pipeline.  Default: apply_batch,
+        which overlaps clustering + reconstruction of file i with the front end of file i+1."""
+        files = [dict(file, uri=f"synthetic_{rank}_{tag}{i}") for i in range(num_files)]
+        last = None
+        if args.sequential:
+            for f in files:
+                last = pipeline(f)
+                if exchange:
+                    exchange_records()
+        elif exchange and args.joint:
+            for f in files:       # one joint clustering per step over the files of all ranks
+                for _, last in pipeline.apply_batch([f], joint_clustering=True):
+                    pass
+        else:
+            for _, last in pipeline(files):
+                if exchange:
+                    exchange_records()
+        return last
 
     def barrier():
         if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup, "w")
     barrier()
     t0 = time.perf_counter()
-    stage_sum = {}
-    for _ in range(args.steps):
-        out = step()
-        for k, v in timer.t.items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    out = run(args.steps, "s")
     barrier()
     elapsed = time.perf_counter() - t0
     if exchange:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- stage split of ONE sequential (un-pipelined, untimed) pass: host clock + device sync per stage
+    timer.start()
+    pipeline(file, hook=timer)
+    stage_sum = dict(timer.t)
+
+    def step():
+        return pipeline(file)
 
     # ---- per-kernel timing of one extra (untimed) step: HIP events on the launch stream
     ffi.prof_enable(True)
@@ -242,35 +394,7 @@ def main():
                              "tflops": round(r["flops"] / ms / 1e9, 2) if ms > 0 else None,
                              "gbs": round(r["bytes"] / ms / 1e6, 1) if ms > 0 else None}
         dom = max(prof, key=lambda k: prof[k]["ms"])
-        r = prof[dom]
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-        # (profiles/r1_traffic.json, produced by tools/pmc_traffic.py; separate FETCH_SIZE / WRITE_SIZE
-        # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fp:
-                traffic = json.load(fp).get(dom, {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
-        if dom in MFMA_KERNELS:
-            ach = r["flops"] / r["ms"] / 1e9
-            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]),
-                    "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4),
-                    "algorithmic_gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3)}
-            if dom in EXECUTED_FLOP_FRACTION:
-                # `achieved` counts the reference operation's flops (direct 3x3 convolution) and may
-                # exceed the MFMA peak; the matrix pipe itself executes this fraction of them
-                ex = ach * EXECUTED_FLOP_FRACTION[dom]
-                roof["mfma_executed"] = {"tflops": round(ex, 2), "frac": round(ex / PEAK_MFMA_F32_TFLOPS, 4),
-                                         "note": "Winograd F(2x2,3x3): 16/36 of the algorithmic multiplies"}
-        else:
-            ach = r["bytes"] / r["ms"] / 1e6
-            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                    "launches": r["launches"], "avg_launch_ms": round(r["ms"] / r["launches"], 4)}
+        roof = roofline_entry(dom, prof[dom])
         total_hours = args.hours * world * args.steps
         line = {
             "metric": "audio-hours/sec (real-time factor) for speaker-diarization-3.1 pipeline",
@@ -284,7 +408,11 @@ def main():
                        "chunks_per_file": int((wav.shape[1] - 160000) // 16000 + 1),
                        "files": world, "parallelism": f"file-per-gpu x{world}"},
             "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
-            "stages_ms_per_step": {k: round(1e3 * v / args.steps, 1) for k, v in stage_sum.items()},
+            "mode": "sequential pipeline(file) calls" if args.sequential else
+                    ("apply_batch(joint_clustering=True) per step" if (exchange and args.joint) else
+                     "pipeline([files]) = apply_batch: clustering/back end of file i overlap the front end "
+                     "of file i+1"),
+            "sequential_stages_ms": {k: round(1e3 * v, 1) for k, v in stage_sum.items()},
             "speakers": len(out.speaker_diarization.labels()),
             "apply_marks_s": {k: round(v, 4) for k, v in getattr(pipeline, "timings", {}).items()},
             "clustering_s": {k: (round(v, 4) if isinstance(v, float) else v)

@@ -142,6 +142,11 @@ class AgglomerativeClustering(BaseClustering):
             t0 = time.perf_counter()
             if (self.method == "centroid" and len(embeddings) >= 2 and self.device is not None
                     and getattr(self.device, "type", None) == "cuda"):
+                if not np.isfinite(embeddings).all():
+                    # scipy.cluster.hierarchy.linkage(X, ...) validates its input the same way; without
+                    # the check a zero-norm / inf embedding (NaN after the normalisation) would walk the
+                    # merge kernel out of bounds
+                    raise ValueError("The condensed distance matrix must contain only finite values.")
                 Z = distance.linkage_centroid(embeddings, self.device)
                 self.timings.update(pdist=0.0, linkage=time.perf_counter() - t0,
                                     num_embeddings=len(embeddings))

@@ -19,6 +19,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 namespace pa {
 
 void set_error(const char* fmt, ...);
+int reserved_cus();  // pa_set_reserved_cus: CUs the persistent kernels leave to other streams
 
 // HIP-event profiler scope (pa_core.cpp): brackets the launches issued while it is alive with two
 // events on `stream`; `flops` / `bytes` are the ALGORITHMIC work of those launches.

@@ -311,18 +311,24 @@ static int launch_conv_r(const float* X, int B, int H, int W, int CIN, const flo
   const int Ho = (H - 1) / S + 1, Wo = (W - 1) / S + 1;
   const int tiles_w = cdiv(Wo, G::TW), tiles_h = cdiv(Ho, TH);
   const size_t lds = (size_t)(G::PATCH + 9 * BN * CLD) * sizeof(float);
-  static int resident = 0;  // workgroups the chip holds at once (2 per CU: LDS- and VGPR-bound)
-  if (!resident) {
+  // workgroups the chip holds at once (2 per CU: LDS- and VGPR-bound); per DEVICE, like the attribute
+  constexpr int MAXDEV = 16;
+  static int resident_of[MAXDEV] = {0}, per_cu_of[MAXDEV] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= MAXDEV) dev = 0;
+  if (!resident_of[dev]) {
     (void)hipFuncSetAttribute((const void*)k_conv3x3<S, TH, TWT, BN, HAS_R>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int dev = 0, cus = 256, per_cu = 2;
-    (void)hipGetDevice(&dev);
+    int cus = 256, per_cu = 2;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3<S, TH, TWT, BN, HAS_R>, 256, lds) !=
             hipSuccess || per_cu < 1)
       per_cu = 2;
-    resident = cus * per_cu;
+    resident_of[dev] = cus * per_cu;
+    per_cu_of[dev] = per_cu;
   }
+  const int resident = resident_of[dev] - reserved_cus() * per_cu_of[dev];
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / BN;
   const long total = (long)tiles_hw * n_tiles * B;
   const int grid = (int)(total < resident ? total : resident);

@@ -338,7 +338,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
   // per-device launch state (the attribute and the CU count belong to a device, not to the process)
   constexpr int MAXDEV = 16;
-  static int resident_of[MAXDEV] = {0};
+  static int resident_of[MAXDEV] = {0}, per_cu_of[MAXDEV] = {0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= MAXDEV) dev = 0;
@@ -351,11 +351,13 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
             hipSuccess || per_cu < 1)
       per_cu = 2;
     resident_of[dev] = cus * per_cu;
+    per_cu_of[dev] = per_cu;
   }
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
   const long num_pb = (long)tiles_hw * B;                    // (pixel tile, image) pairs
   const long total = ((num_pb + 7) / 8) * 8 * n_tiles;       // padded to whole XCD stripes
-  const int grid = (int)(total < resident_of[dev] ? total : resident_of[dev]);
+  const int resident = resident_of[dev] - reserved_cus() * per_cu_of[dev];
+  const int grid = (int)(total < resident ? total : resident);
   hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R>), dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift,
                      R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, (int)num_pb);
   return 0;

@@ -442,12 +442,9 @@ int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t
   // the merge loop is O(N^2) memory traffic in total; algorithmic bytes ~ 3 rows of 8*N per merge
   pa::ProfScope prof("k_linkage_centroid", stream, 9.0 * n * (double)n, 24.0 * n * (double)n);
   if (n <= 65535 && lds16 <= pa::LK_LDS_MAX) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)pa::k_linkage_centroid<unsigned short, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa::LK_LDS_MAX);
-      attr = true;
-    }
+    // (set on every call: the attribute belongs to the current device, not to the process)
+    (void)hipFuncSetAttribute((const void*)pa::k_linkage_centroid<unsigned short, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa::LK_LDS_MAX);
     hipLaunchKernelGGL((pa::k_linkage_centroid<unsigned short, true>), dim3(1), dim3(pa::LK_T), lds16, st,
                        D, n, Z, size, cid, hv, kbi, ibk, nb, stats);
   } else {

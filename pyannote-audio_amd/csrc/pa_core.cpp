@@ -21,6 +21,12 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// CUs the persistent (grid = resident workgroups) kernels leave free, so that a long single-workgroup
+// kernel on another stream -- the dendrogram merge of the previous file -- does not push two of their
+// statically partitioned workgroups into a second round (pa_set_reserved_cus).
+static int g_reserved_cus = 0;
+int reserved_cus() { return g_reserved_cus; }
+
 // ---------------------------------------------------------------------------------------------
 // Profiler: when enabled, every kernel launcher brackets its launch with two hipEvents recorded on
 // the SAME stream the kernel runs on (torch.cuda.Event would only see torch's current stream).
@@ -64,6 +70,9 @@ ProfScope::~ProfScope() {
 }  // namespace pa
 
 extern "C" {
+
+void pa_set_reserved_cus(int n) { pa::g_reserved_cus = n < 0 ? 0 : n; }
+
 int pa_version(void) { return 101; }
 const char* pa_last_error(void) { return pa::g_err; }
 

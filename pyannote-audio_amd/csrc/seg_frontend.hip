@@ -247,12 +247,9 @@ int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, i
   const int P = L / 3;
   if (B <= 0 || P <= 0) return 0;
   const size_t lds = (pa::SINC_XS + 80 * pa::SINC_OS) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    attr = true;
-  }
+  // (set on every call: the attribute belongs to the current device, not to the process)
+  (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
   pa::ProfScope prof("k_sinc_fir_pool", stream, 2.0 * B * 80 * 251 * (3.0 * P),
                      4.0 * B * N + 4.0 * B * 80 * P);
   hipLaunchKernelGGL(pa::k_sinc_fir_pool, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(320), lds,

@@ -24,6 +24,7 @@ def _use_gpu(device, n: int) -> bool:
     return True
 
 
+@ffi.on_device(lambda X, device=None: device)
 def pdist_euclidean(X: np.ndarray, device=None) -> np.ndarray:
     """condensed float64 Euclidean distance matrix of the rows of X (any float dtype)."""
     n = X.shape[0]
@@ -36,6 +37,7 @@ def pdist_euclidean(X: np.ndarray, device=None) -> np.ndarray:
     return out.cpu().numpy()
 
 
+@ffi.on_device(lambda X, device: device)
 def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") entirely on the GPU:
     float64 pdist (`pa_pdist_f64`) feeds the persistent merge kernel (`pa_linkage_centroid_f64`) without
@@ -58,6 +60,7 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
 last_linkage_stats = None
 
 
+@ffi.on_device(lambda A, B, metric="cosine", device=None: device)
 def cdist(A: np.ndarray, B: np.ndarray, metric: str = "cosine", device=None) -> np.ndarray:
     if metric != "cosine" or not _use_gpu(device, A.shape[0]):
         return _scipy_cdist(A, B, metric=metric)

@@ -46,6 +46,7 @@ class EmbeddingEngine:
             self._idx_cache[key] = idx.to(self.pack.device)
         return self._idx_cache[key]
 
+    @ffi.on_device(lambda self, *a, **k: self.pack.device)
     def forward_strided(self, wav: torch.Tensor, chunk_stride: int, num_chunks: int, num_samples: int,
                         masks: torch.Tensor | None = None) -> torch.Tensor:
         """wav: 1-D fp32 device tensor; masks: (C, S, Fm) fp32 device or None -> (C, S, D) fp32."""

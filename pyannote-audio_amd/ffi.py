@@ -92,6 +92,8 @@ def load():
     lib.pa_lstm_rec.argtypes = [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]
     lib.pa_classifier.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp,
                                   C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]
+    lib.pa_set_reserved_cus.argtypes = [C.c_int]
+    lib.pa_set_reserved_cus.restype = None
     lib.pa_prof_enable.argtypes = [C.c_int]
     lib.pa_prof_enable.restype = None
     lib.pa_prof_report.argtypes = [C.c_char_p, C.c_size_t]
@@ -153,7 +155,29 @@ def ptr(t: torch.Tensor | None):
 
 
 def stream():
+    """HIP stream the kernels are launched on = torch's current stream of the CURRENT device; every
+    launch path runs under `on_device` so that this is the device the tensors live on."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(get_device):
+    """Decorator: run the wrapped launcher with `get_device(*args, **kwargs)` as the current HIP device
+    (kernel launches, hipMemsetAsync and the profiler's events go to the current device's context;
+    with `pipeline.to(torch.device("cuda:1"))` the tensors are on GPU 1 while the caller's current
+    device may still be 0)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            dev = get_device(*args, **kwargs)
+            if dev is not None and getattr(dev, "type", None) == "cuda" and torch.cuda.is_available() \
+                    and dev.index is not None and dev.index != torch.cuda.current_device():
+                with torch.cuda.device(dev):
+                    return fn(*args, **kwargs)
+            return fn(*args, **kwargs)
+        return wrapper
+    return deco
 
 
 def check(rc: int, what: str = ""):

@@ -36,6 +36,7 @@ def as_device_segmentation(seg, device: torch.device) -> torch.Tensor:
     return torch.from_numpy(np.nan_to_num(np.asarray(seg), nan=0.0).astype(np.uint8)).to(device)
 
 
+@ffi.on_device(lambda seg, *a, **k: seg.device)
 def chunk_stats(seg: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """-> active (C,S) int32 = #frames speaker s is on, clean (C,S) int32 = #frames it speaks alone."""
     C, F, S = seg.shape
@@ -46,6 +47,7 @@ def chunk_stats(seg: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return active, clean
 
 
+@ffi.on_device(lambda seg, *a, **k: seg.device)
 def embedding_masks(seg: torch.Tensor, clean: torch.Tensor, exclude_overlap: bool,
                     min_num_frames: int) -> torch.Tensor:
     C, F, S = seg.shape
@@ -56,6 +58,7 @@ def embedding_masks(seg: torch.Tensor, clean: torch.Tensor, exclude_overlap: boo
     return masks
 
 
+@ffi.on_device(lambda seg, *a, **k: seg.device)
 def speaker_count(seg: torch.Tensor, chunks: SlidingWindow, frames: SlidingWindow
                   ) -> SlidingWindowFeature:
     """pipelines/utils/diarization.py:150-185 with warm_up=(0, 0)."""
@@ -74,6 +77,7 @@ class Reconstructor:
     """speaker_diarization.py:480-528 + diarization.py:221-268: cluster activations are accumulated
     once, then discretised for any per-frame cap (regular and exclusive diarization share them)."""
 
+    @ffi.on_device(lambda self, seg, *a, **k: seg.device)
     def __init__(self, seg: torch.Tensor, chunks: SlidingWindow, frames: SlidingWindow,
                  hard_clusters: np.ndarray, count: np.ndarray):
         C, F, S = seg.shape
@@ -94,6 +98,7 @@ class Reconstructor:
                                                     self.K, T, ffi.ptr(self.act), ffi.stream()),
                   "pa_cluster_activations")
 
+    @ffi.on_device(lambda self, *a, **k: self.act.device)
     def discretize(self, cap: int = 255) -> SlidingWindowFeature:
         """Top-min(count[t], cap) clusters per frame.  Frames whose selection boundary falls inside a
         group of EQUAL activations are re-decided with `np.argsort(-activations)` -- the reference's

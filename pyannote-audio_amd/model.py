@@ -104,10 +104,17 @@ class _Opaque:
 
 
 class _ShimUnpickler(pickle.Unpickler):
-    """Restricted unpickler for Lightning / pyannote.audio checkpoints when neither package is
-    installed: maps the handful of foreign classes to local stand-ins."""
+    """Restricted unpickler for Lightning / pyannote.audio checkpoints: foreign classes of the
+    pyannote / lightning ecosystem map to local stand-ins, tensor / container plumbing comes from an
+    allow-list of modules, and EVERYTHING ELSE raises `UnpicklingError` -- a crafted checkpoint cannot
+    resolve `os.system`, `builtins.eval` and the like (the reference's plain `weights_only=False`
+    load can)."""
 
     _LOCAL = {"Specifications": Specifications, "Problem": Problem, "Resolution": Resolution}
+    _SAFE_MODULES = ("torch", "collections", "numpy", "_codecs", "typing", "enum", "datetime",
+                     "pathlib", "argparse", "omegaconf", "copyreg")
+    _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str",
+                      "bytes", "bytearray", "complex", "slice", "range", "object", "getattr"}
 
     def find_class(self, module, name):
         if module.startswith("pyannote.audio") and name in self._LOCAL:
@@ -117,7 +124,18 @@ class _ShimUnpickler(pickle.Unpickler):
         if module.startswith(("pyannote.", "lightning", "pytorch_lightning", "torchmetrics",
                               "pytorch_metric_learning", "asteroid")):
             return _Opaque
-        return super().find_class(module, name)
+        if module == "builtins":
+            if name in self._SAFE_BUILTINS and name != "getattr":
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"checkpoint references builtins.{name}: refused")
+        root = module.split(".")[0]
+        if root in self._SAFE_MODULES and not (root == "torch" and name in ("load", "hub")):
+            if root == "numpy" and name in ("load", "loads", "fromfile", "memmap"):
+                raise pickle.UnpicklingError(f"checkpoint references {module}.{name}: refused")
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(
+            f"checkpoint references {module}.{name}, which is not on the allow-list of the "
+            "pyannote_audio_amd checkpoint reader")
 
 
 _shim_pickle = types.ModuleType("pyannote_audio_amd._shim_pickle")

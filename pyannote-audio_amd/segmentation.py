@@ -38,6 +38,7 @@ class SegmentationEngine:
     def release_workspace(self):
         self._ws = None
 
+    @ffi.on_device(lambda self, *a, **k: self.pack.device)
     def forward_strided(self, wav: torch.Tensor, chunk_stride: int, num_chunks: int, num_samples: int,
                         want_logp: bool = True, want_multilabel: bool = True):
         """wav: 1-D fp32 device tensor; chunk c = wav[c*stride : c*stride + num_samples] (zero padded

@@ -1,25 +1,35 @@
 """Speaker diarization pipeline (`pyannote/speaker-diarization-3.1` configuration), MI355X native.
 
-Mirrors pipelines/speaker_diarization.py (class :127-279, get_segmentations :305-330, get_embeddings
-:332-478, reconstruct :480-528, apply :530-784).  Same stages, same outputs; different mechanics:
-  * the waveform is uploaded once; segmentation and embedding kernels gather their chunks in HBM;
-  * the ResNet backbone runs once per chunk and is pooled for the 3 local speakers (the reference runs
-    it once per (chunk, speaker) on identical audio, :417-425);
-  * overlap-add / top-k / hysteresis steps are array operations instead of per-frame Python loops;
-  * `shard=(rank, world_size)` splits the chunk range across GPUs; per-chunk results are exchanged
-    with one RCCL all-gather (parallel.py)."""
+Public surface = the reference's (pipelines/speaker_diarization.py: constructor :127-279, `apply`
+:530-784, hooks, `DiarizeOutput` :63-124, `get_segmentations` :305-330, `get_embeddings` :332-478,
+`reconstruct` :480-528; `apply_batch` is the hook `core/pipeline.py:489-508` looks for).  Inside, the
+work is organised as three device stages instead of the reference's one long method:
+
+  front end   waveform -> hard segmentations (C,F,S) + speaker count + embeddings (C,S,D), all produced
+              by the HIP library from ONE upload of the waveform (`_front_end`, stream 0)
+  clustering  embeddings of one file -- or of MANY files, possibly gathered from all ranks
+              (`apply_batch(..., joint_clustering=True)`, BASELINE.json configs[4]) -> cluster ids
+  back end    cluster ids -> overlap-add reconstruction, top-count discretisation, annotations
+              (`_back_end`)
+
+`apply_batch` pipelines files: clustering + back end of file i run on a second HIP stream in a worker
+thread while the front end of file i+1 occupies the rest of the chip (the dendrogram merge is one
+persistent workgroup on one CU: 15 % of a sequential step with 255 CUs idle).  `shard=(rank, world)`
+(parallel.set_shard) splits the chunk range of ONE file across GPUs instead."""
 from __future__ import annotations
 
 import math
 import textwrap
 import time
 import warnings
-from dataclasses import dataclass
-from typing import Any, Callable, Optional
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+from typing import Any, Callable, Iterable, Iterator, List, Optional, Tuple
 
 import numpy as np
 import torch
 
+from . import ffi
 from . import frames as frame_ops
 from . import parallel
 from .agglomerative import Clustering
@@ -47,6 +57,26 @@ class DiarizeOutput:
                 "exclusive_diarization": turns(self.exclusive_speaker_diarization)}
 
 
+@dataclass
+class _FrontEnd:
+    """Everything the later stages need about one file.  Device tensors stay referenced here so that
+    the back end (possibly on another stream / thread) never sees recycled memory."""
+    file: dict
+    chunks: SlidingWindow                          # chunk grid of the WHOLE file
+    segmentations: SlidingWindowFeature            # host, float32 {0,1}, (C, F, S)
+    dev_seg: torch.Tensor                          # device, uint8, (C, F, S)
+    count: SlidingWindowFeature                    # host, uint8, (T, 1)
+    active: Optional[np.ndarray] = None            # (C, S) frames a local speaker is on
+    clean: Optional[np.ndarray] = None             # (C, S) frames it speaks alone
+    embeddings: Optional[np.ndarray] = None        # host, float32, (C, S, D)
+    dev_emb: Optional[torch.Tensor] = None
+    marks: list = field(default_factory=list)
+
+    @property
+    def silent(self) -> bool:
+        return self.embeddings is None
+
+
 class SpeakerDiarization(Pipeline):
     def __init__(self, legacy: bool = False, segmentation: PipelineModel = None,
                  segmentation_step: float = 0.1, embedding: PipelineModel = None,
@@ -60,38 +90,42 @@ class SpeakerDiarization(Pipeline):
                              "instances): Hugging Face defaults cannot be downloaded in this build.")
         self.legacy = legacy
         self.segmentation_model = segmentation
-        model: Model = get_model(segmentation, token=token, cache_dir=cache_dir)
         self.segmentation_step = segmentation_step
         self.embedding = embedding
         self.embedding_batch_size = embedding_batch_size
         self.embedding_exclude_overlap = embedding_exclude_overlap
-        self.plda = plda  # only consumed by VBxClustering (next row)
+        self.plda = plda
         self.klustering = clustering
         self.der_variant = der_variant or {"collar": 0.0, "skip_overlap": False}
+        if clustering not in Clustering.__members__:
+            raise ValueError(f"clustering must be one of [{', '.join(list(Clustering.__members__))}]")
 
-        segmentation_duration = model.specifications.duration
-        self._segmentation = Inference(model, duration=segmentation_duration,
-                                       step=self.segmentation_step * segmentation_duration,
+        seg_model: Model = get_model(segmentation, token=token, cache_dir=cache_dir)
+        chunk_duration = seg_model.specifications.duration
+        self._segmentation = Inference(seg_model, duration=chunk_duration,
+                                       step=self.segmentation_step * chunk_duration,
                                        skip_aggregation=True, batch_size=segmentation_batch_size)
-        if self._segmentation.model.specifications.powerset:
-            self.segmentation = ParamDict(min_duration_off=Uniform(0.0, 1.0))
-        else:
-            self.segmentation = ParamDict(threshold=Uniform(0.1, 0.9),
-                                          min_duration_off=Uniform(0.0, 1.0))
-        if self.klustering == "OracleClustering":
-            metric = "not_applicable"
-        else:
+        tunables = {"min_duration_off": Uniform(0.0, 1.0)}
+        if not seg_model.specifications.powerset:
+            tunables = {"threshold": Uniform(0.1, 0.9), **tunables}
+        self.segmentation = ParamDict(**tunables)
+
+        metric = "not_applicable"
+        if clustering != "OracleClustering":
             self._embedding = PretrainedSpeakerEmbedding(self.embedding, token=token,
                                                          cache_dir=cache_dir)
             self._audio = Audio(sample_rate=self._embedding.sample_rate, mono="downmix")
             metric = self._embedding.metric
-        try:
-            Klustering = Clustering[clustering]
-        except KeyError:
-            raise ValueError(
-                f"clustering must be one of [{', '.join(list(Clustering.__members__))}]")
-        self.clustering = Klustering.value(metric=metric)
+        self.clustering = Clustering[clustering].value(**self._clustering_kwargs(clustering, metric))
         self._expects_num_speakers = self.clustering.expects_num_clusters
+        self.timings: dict = {}
+        self._last_front: Optional[_FrontEnd] = None
+
+    def _clustering_kwargs(self, name: str, metric: str) -> dict:
+        kwargs = {"metric": metric}
+        if name == "VBxClustering":
+            kwargs["plda"] = self.plda
+        return kwargs
 
     @property
     def segmentation_batch_size(self) -> int:
@@ -116,125 +150,101 @@ class SpeakerDiarization(Pipeline):
             yield f"SPEAKER_{speaker:02d}"
             speaker += 1
 
-    # -----------------------------------------------------------------------------------------
-    def _load(self, file) -> torch.Tensor:
-        """whole file as a (1, n) fp32 tensor at the model's rate (core/inference.py:403)."""
-        waveform, sample_rate = self._audio(file)
-        return waveform
+    # ------------------------------------------------------------------------------ geometry helpers
+    @property
+    def _frames(self) -> SlidingWindow:
+        return self._segmentation.model.receptive_field
 
-    def get_segmentations(self, file, hook=None, waveform: Optional[torch.Tensor] = None,
-                          chunk_range=None) -> SlidingWindowFeature:
-        """speaker_diarization.py:305-330"""
-        if hook is not None:
-            import functools
-            hook = functools.partial(hook, "segmentation", None)
-        if waveform is None:
-            waveform = self._load(file)
-        return self._segmentation.slide(waveform, self._audio.sample_rate, hook=hook,
-                                        chunk_range=chunk_range)
+    def _chunk_grid(self) -> SlidingWindow:
+        return SlidingWindow(start=0.0, duration=self._segmentation.duration, step=self._segmentation.step)
 
-    def _device_segmentation(self, binary_segmentations: SlidingWindowFeature) -> torch.Tensor:
-        """(C, F, S) uint8 device copy of the hard segmentations: the tensor the segmentation kernels
-        just produced when it is still the same data, an upload otherwise (sharded / user-supplied)."""
-        dev = self._segmentation.last_device_output
-        if dev is None or tuple(dev.shape) != tuple(binary_segmentations.data.shape) \
-                or self._segmentation.last_host_output is not binary_segmentations.data:
-            dev = frame_ops.as_device_segmentation(binary_segmentations.data, self._segmentation.device)
-        cache = getattr(self, "_stats_cache", None)
-        if cache is None or cache[0] is not dev:
-            self._stats_cache = (dev, None)
-        return dev
-
-    def _chunk_stats(self, dev_bin: torch.Tensor):
-        cache = getattr(self, "_stats_cache", None)
-        if cache is not None and cache[0] is dev_bin and cache[1] is not None:
-            return cache[1]
-        stats = frame_ops.chunk_stats(dev_bin)
-        self._stats_cache = (dev_bin, stats)
-        return stats
-
-    def get_embeddings(self, file, binary_segmentations: SlidingWindowFeature,
-                       exclude_overlap: bool = False, hook: Optional[Callable] = None,
-                       waveform: Optional[torch.Tensor] = None, chunk_range=None):
-        """speaker_diarization.py:332-478 -> (num_chunks, num_speakers, dimension) float32."""
-        device = self._embedding.device
-        duration = binary_segmentations.sliding_window.duration
-        num_chunks, num_frames, num_speakers = binary_segmentations.data.shape
-        if waveform is None:
-            waveform = self._load(file)
-        sr = self._embedding.sample_rate
-        window = self._audio.get_num_samples(duration, sr)
-        step = round(binary_segmentations.sliding_window.step * sr)
-        begin = 0 if chunk_range is None else chunk_range[0]
-        dev_bin = self._device_segmentation(binary_segmentations)
-        _, clean = self._chunk_stats(dev_bin)
-        if exclude_overlap:
-            # speaker_diarization.py:375-382
-            min_num_samples = self._embedding.min_num_samples
-            num_samples = duration * self._embedding.sample_rate
-            min_num_frames = math.ceil(num_frames * min_num_samples / num_samples)
-        else:
-            min_num_frames = -1
-        masks = frame_ops.embedding_masks(dev_bin, clean, exclude_overlap, min_num_frames)
-        batch_count = math.ceil(num_chunks * num_speakers / self.embedding_batch_size)
-        if hook is not None:
-            hook("embeddings", None, total=batch_count, completed=0)
-        wav = waveform.to(device, torch.float32).contiguous().view(-1)
-        engine = self._embedding.model_.engine
-        emb = engine.forward_strided(wav[begin * step:], step, num_chunks, window, masks)
-        self._last_exchange = (dev_bin, emb)
-        embeddings = emb.cpu().numpy()
-        if hook is not None:
-            hook("embeddings", embeddings, total=batch_count, completed=batch_count)
-        return embeddings
-
-    def last_exchange_payload(self, device: torch.device) -> torch.Tensor:
-        """Device-resident fused byte records of the last file's per-chunk results -- uint8 hard
-        segmentation (F*S bytes) followed by the fp32 embeddings (S*D*4 bytes) per chunk -- i.e. the
-        send buffer of the multi-file all-gather (parallel.all_gather_chunks uses the same record)."""
-        seg, emb = self._last_exchange
-        C = seg.shape[0]
-        seg_b = seg.to(torch.uint8).reshape(C, -1)
-        emb_b = emb.contiguous().view(torch.uint8).reshape(C, -1)
-        return torch.cat([seg_b, emb_b], dim=1).contiguous()
-
-    def reconstruct(self, segmentations: SlidingWindowFeature, hard_clusters: np.ndarray,
-                    count: SlidingWindowFeature) -> SlidingWindowFeature:
-        """speaker_diarization.py:480-528 (per chunk, activation of cluster k = max over the local
-        speakers assigned to k) followed by to_diarization (diarization.py:221-268), on the GPU."""
-        rec = frame_ops.Reconstructor(self._device_segmentation(segmentations),
-                                      segmentations.sliding_window,
-                                      self._segmentation.model.receptive_field, hard_clusters,
-                                      count.data)
-        return rec.discretize()
-
-    # -----------------------------------------------------------------------------------------
-    def apply(self, file: AudioFile, num_speakers: Optional[int] = None,
-              min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
-              hook: Optional[Callable] = None, **kwargs):
-        """speaker_diarization.py:530-784"""
-        if len(kwargs) > 0:
-            warnings.warn(f"Ignoring unexpected keyword arguments: {', '.join(list(kwargs.keys()))}")
-        hook = self.setup_hook(file, hook=hook)
-        num_speakers, min_speakers, max_speakers = set_num_speakers(
-            num_speakers=num_speakers, min_speakers=min_speakers, max_speakers=max_speakers)
-        if self._expects_num_speakers and num_speakers is None:
-            raise ValueError(f"num_speakers must be provided when using {self.klustering} clustering")
-
-        # no CPU path: every stage below runs through libpyannote_amd.so on a gfx950 device
-        from . import ffi
+    def _require_device(self) -> torch.device:
+        """no CPU path: every stage runs through libpyannote_amd.so on a gfx950 device"""
         ffi.require_gpu()
         device = getattr(self.clustering, "device", None)
         if device is None or getattr(device, "type", None) != "cuda":
             raise RuntimeError("SpeakerDiarization must be moved to the GPU first: "
                                "pipeline.to(torch.device('cuda')) -- there is no CPU fallback")
+        return device
+
+    def _load(self, file) -> torch.Tensor:
+        """whole file as a (1, n) fp32 tensor at the model's rate (core/inference.py:403)."""
+        waveform, _ = self._audio(file)
+        return waveform
+
+    # --------------------------------------------------------------------- reference-named stage API
+    def get_segmentations(self, file, hook=None, waveform: Optional[torch.Tensor] = None,
+                          chunk_range=None) -> SlidingWindowFeature:
+        """speaker_diarization.py:305-330"""
+        progress = None
+        if hook is not None:
+            def progress(**kw):
+                return hook("segmentation", None, **kw)
+        if waveform is None:
+            waveform = self._load(file)
+        return self._segmentation.slide(waveform, self._audio.sample_rate, hook=progress,
+                                        chunk_range=chunk_range)
+
+    def _min_num_frames(self, num_frames: int, duration: float, exclude_overlap: bool) -> int:
+        """speaker_diarization.py:375-382: shortest clean mask that still yields an embedding"""
+        if not exclude_overlap:
+            return -1
+        sr = self._embedding.sample_rate
+        return math.ceil(num_frames * self._embedding.min_num_samples / (duration * sr))
+
+    def _embed(self, waveform: torch.Tensor, dev_seg: torch.Tensor, chunks: SlidingWindow,
+               first_chunk: int, exclude_overlap: bool, hook: Optional[Callable]):
+        """masks on the device -> ONE backbone pass per chunk, pooled for every local speaker
+        -> ((C, S, D) device tensor, clean-frame counts).  Replaces speaker_diarization.py:384-476."""
+        C, F, S = dev_seg.shape
+        sr = self._embedding.sample_rate
+        window = self._audio.get_num_samples(chunks.duration, sr)
+        step = round(chunks.step * sr)
+        active, clean = frame_ops.chunk_stats(dev_seg)
+        masks = frame_ops.embedding_masks(dev_seg, clean, exclude_overlap,
+                                          self._min_num_frames(F, chunks.duration, exclude_overlap))
+        batches = math.ceil(C * S / self.embedding_batch_size)
+        if hook is not None:
+            hook("embeddings", None, total=batches, completed=0)
+        wav = waveform.to(self._embedding.device, torch.float32).contiguous().view(-1)
+        engine = self._embedding.model_.engine
+        emb = engine.forward_strided(wav[first_chunk * step:], step, C, window, masks)
+        return emb, active, clean, batches
+
+    def get_embeddings(self, file, binary_segmentations: SlidingWindowFeature,
+                       exclude_overlap: bool = False, hook: Optional[Callable] = None,
+                       waveform: Optional[torch.Tensor] = None, chunk_range=None):
+        """speaker_diarization.py:332-478 -> (num_chunks, num_speakers, dimension) float32."""
+        if waveform is None:
+            waveform = self._load(file)
+        dev_seg = frame_ops.as_device_segmentation(binary_segmentations.data, self._embedding.device)
+        emb, _, _, batches = self._embed(waveform, dev_seg, binary_segmentations.sliding_window,
+                                         0 if chunk_range is None else chunk_range[0],
+                                         exclude_overlap, hook)
+        embeddings = emb.cpu().numpy()
+        if hook is not None:
+            hook("embeddings", embeddings, total=batches, completed=batches)
+        return embeddings
+
+    def reconstruct(self, segmentations: SlidingWindowFeature, hard_clusters: np.ndarray,
+                    count: SlidingWindowFeature) -> SlidingWindowFeature:
+        """speaker_diarization.py:480-528 (per chunk, activation of cluster k = max over the local
+        speakers assigned to k) followed by to_diarization (diarization.py:221-268), on the GPU."""
+        dev_seg = frame_ops.as_device_segmentation(segmentations.data, self._segmentation.device)
+        return frame_ops.Reconstructor(dev_seg, segmentations.sliding_window, self._frames,
+                                       hard_clusters, count.data).discretize()
+
+    def last_exchange_payload(self, device: torch.device) -> torch.Tensor:
+        """Device-resident record buffer (parallel.pack_records) of the last file's front end: the send
+        buffer of the multi-file all-gather."""
+        front = self._last_front
+        return parallel.pack_records(front.dev_seg, front.dev_emb).to(device)
+
+    # ---------------------------------------------------------------------------------- front end
+    def _front_end(self, file: dict, hook: Callable) -> _FrontEnd:
         marks = [("start", time.perf_counter())]
-
-        def mark(name):
-            marks.append((name, time.perf_counter()))
-
         waveform = self._load(file)
-        mark("load")
+        marks.append(("load", time.perf_counter()))
         shard = parallel.current_shard()
         sr = self._audio.sample_rate
         window = self._segmentation.model.audio.get_num_samples(self._segmentation.duration)
@@ -242,108 +252,251 @@ class SpeakerDiarization(Pipeline):
         n_full, has_last = Inference.num_chunks(waveform.shape[1], window, step)
         total_chunks = n_full + has_last
         chunk_range = parallel.chunk_range(total_chunks, shard)
+        chunks = self._chunk_grid()
 
-        segmentations = self.get_segmentations(file, hook=hook, waveform=waveform,
-                                               chunk_range=chunk_range)
-        mark("segmentation")
-        if shard.world_size == 1:
-            hook("segmentation", segmentations)
-        num_chunks, num_frames, local_num_speakers = segmentations.data.shape
-        binarized_segmentations = segmentations  # powerset models are already hard (:598-600)
+        segmentations = self.get_segmentations(file, hook=hook, waveform=waveform, chunk_range=chunk_range)
+        dev_seg = self._segmentation.last_device_output
+        marks.append(("segmentation", time.perf_counter()))
 
-        embeddings = None
+        dev_emb = active = clean = None
         if shard.world_size > 1:
             # every rank embeds its own chunk range, then ONE all-gather of (segmentation, embedding)
-            embeddings = self.get_embeddings(file, binarized_segmentations,
-                                             exclude_overlap=self.embedding_exclude_overlap,
-                                             waveform=waveform, chunk_range=chunk_range)
-            seg_all, embeddings = parallel.all_gather_chunks(segmentations.data, embeddings,
-                                                             total_chunks, shard,
-                                                             self._segmentation.device)
-            segmentations = SlidingWindowFeature(
-                seg_all, SlidingWindow(start=0.0, duration=self._segmentation.duration,
-                                       step=self._segmentation.step))
-            binarized_segmentations = segmentations
-            hook("segmentation", segmentations)
-            num_chunks = total_chunks
+            # records that never leave the device with RCCL
+            local_emb, _, _, _ = self._embed(waveform, dev_seg, segmentations.sliding_window,
+                                             chunk_range[0], self.embedding_exclude_overlap, None)
+            dev_seg, dev_emb = parallel.all_gather_chunks(dev_seg, local_emb, total_chunks, shard,
+                                                          self._segmentation.device)
+            dev_seg = dev_seg.contiguous()
+            segmentations = SlidingWindowFeature(dev_seg.cpu().numpy().astype(np.float32), chunks)
+        hook("segmentation", segmentations)
 
-        dev_seg = self._device_segmentation(binarized_segmentations)
-        count = frame_ops.speaker_count(dev_seg, binarized_segmentations.sliding_window,
-                                        self._segmentation.model.receptive_field)
-        mark("speaker_counting")
+        count = frame_ops.speaker_count(dev_seg, chunks, self._frames)
+        marks.append(("speaker_counting", time.perf_counter()))
         hook("speaker_counting", count)
-
+        front = _FrontEnd(file=file, chunks=chunks, segmentations=segmentations, dev_seg=dev_seg,
+                          count=count, marks=marks)
         if np.nanmax(count.data) == 0.0:
-            output = DiarizeOutput(
-                speaker_diarization=Annotation(uri=file["uri"]),
-                exclusive_speaker_diarization=Annotation(uri=file["uri"]),
-                speaker_embeddings=np.zeros((0, self._embedding.dimension)))
-            return output.speaker_diarization if self.legacy else output
+            return front                       # nobody speaks: no embeddings (:617-629)
 
-        if embeddings is None:
-            embeddings = self.get_embeddings(file, binarized_segmentations,
-                                             exclude_overlap=self.embedding_exclude_overlap, hook=hook,
-                                             waveform=waveform)
-        mark("embeddings")
-        hook("embeddings", embeddings)
+        if dev_emb is None:
+            dev_emb, active, clean, batches = self._embed(waveform, dev_seg, chunks, 0,
+                                                          self.embedding_exclude_overlap, hook)
+            front.embeddings = dev_emb.cpu().numpy()
+            if hook is not None:
+                hook("embeddings", front.embeddings, total=batches, completed=batches)
+        else:
+            active, clean = frame_ops.chunk_stats(dev_seg)
+            front.embeddings = dev_emb.cpu().numpy()
+        front.dev_emb = dev_emb
+        front.active, front.clean = active.cpu().numpy(), clean.cpu().numpy()
+        marks.append(("embeddings", time.perf_counter()))
+        hook("embeddings", front.embeddings)
+        self._last_front = front
+        return front
 
-        active_frames, clean_frames = (t.cpu().numpy() for t in self._chunk_stats(dev_seg))
-        hard_clusters, _, centroids = self.clustering(
-            embeddings=embeddings, segmentations=binarized_segmentations, num_clusters=num_speakers,
-            min_clusters=min_speakers, max_clusters=max_speakers, file=file,
-            frames=self._segmentation.model.receptive_field, num_clean_frames=clean_frames)
-        mark("clustering")
-        num_different_speakers = np.max(hard_clusters) + 1
-        if num_different_speakers < min_speakers or num_different_speakers > max_speakers:
+    # ----------------------------------------------------------------------------------- back end
+    def _empty_output(self, file: dict):
+        output = DiarizeOutput(speaker_diarization=Annotation(uri=file["uri"]),
+                               exclusive_speaker_diarization=Annotation(uri=file["uri"]),
+                               speaker_embeddings=np.zeros((0, self._embedding.dimension)))
+        return output.speaker_diarization if self.legacy else output
+
+    def _cluster_one(self, front: _FrontEnd, num_speakers, min_speakers, max_speakers):
+        hard, _, centroids = self.clustering(
+            embeddings=front.embeddings, segmentations=front.segmentations, num_clusters=num_speakers,
+            min_clusters=min_speakers, max_clusters=max_speakers, file=front.file, frames=self._frames,
+            num_clean_frames=front.clean)
+        return hard, centroids
+
+    def _back_end(self, front: _FrontEnd, hard_clusters: np.ndarray, centroids: Optional[np.ndarray],
+                  min_speakers, max_speakers, hook: Callable):
+        file = front.file
+        marks = front.marks
+        marks.append(("clustering", time.perf_counter()))
+        found = int(np.max(hard_clusters)) + 1
+        if found < min_speakers or found > max_speakers:
             warnings.warn(textwrap.dedent(f"""
-                The detected number of speakers ({num_different_speakers}) for {file["uri"]} is outside
+                The detected number of speakers ({found}) for {file["uri"]} is outside
                 the given bounds [{min_speakers}, {max_speakers}]. This can happen if the
                 given audio file is too short to contain {min_speakers} or more speakers.
                 Try to lower the desired minimal number of speakers.
                 """))
-        count.data = np.minimum(count.data, max_speakers).astype(np.int8)
+        # a local speaker that never speaks belongs to no cluster (:681-685)
+        hard_clusters = np.where(front.active == 0, -2, hard_clusters)
+        capped = np.minimum(front.count.data, max_speakers).astype(np.int8)          # (:676)
+        rec = frame_ops.Reconstructor(front.dev_seg, front.chunks, self._frames, hard_clusters, capped)
+        regular = rec.discretize()
+        marks.append(("reconstruction", time.perf_counter()))
+        hook("discrete_diarization", regular)
+        exclusive = rec.discretize(cap=1)                                            # (:702-707)
 
-        inactive_speakers = active_frames == 0
-        hard_clusters[inactive_speakers] = -2
-
-        reconstructor = frame_ops.Reconstructor(dev_seg, segmentations.sliding_window,
-                                                self._segmentation.model.receptive_field,
-                                                hard_clusters, count.data)
-        discrete_diarization = reconstructor.discretize()
-        mark("reconstruction")
-        hook("discrete_diarization", discrete_diarization)
-        diarization = to_annotation(discrete_diarization, min_duration_on=0.0,
-                                    min_duration_off=self.segmentation.min_duration_off)
-        diarization.uri = file["uri"]
-
-        count.data = np.minimum(count.data, 1).astype(np.int8)
-        exclusive_discrete_diarization = reconstructor.discretize(cap=1)
-        exclusive_diarization = to_annotation(exclusive_discrete_diarization, min_duration_on=0.0,
-                                              min_duration_off=self.segmentation.min_duration_off)
-        exclusive_diarization.uri = file["uri"]
-
-        # hypothesised speakers -> SPEAKER_00, SPEAKER_01, ... in labels() order (:730-737).
-        # (mapping onto a reference annotation, :718-729, needs pyannote.metrics: out of scope)
-        mapping = {label: expected_label
-                   for label, expected_label in zip(diarization.labels(), self.classes())}
-        diarization = diarization.rename_labels(mapping=mapping)
-        exclusive_diarization = exclusive_diarization.rename_labels(mapping=mapping)
-        mark("annotation")
-        # wall-clock per stage of the last call (host clock, no device synchronisation)
+        gap = self.segmentation.min_duration_off
+        diarization = to_annotation(regular, min_duration_on=0.0, min_duration_off=gap)
+        exclusive_diarization = to_annotation(exclusive, min_duration_on=0.0, min_duration_off=gap)
+        # cluster ids -> SPEAKER_00, SPEAKER_01, ... in labels() order (:730-737); the mapping onto a
+        # reference annotation (:718-729) needs pyannote.metrics and is out of scope
+        labels = diarization.labels()
+        names = dict(zip(labels, self.classes()))
+        diarization = diarization.rename_labels(mapping=names)
+        exclusive_diarization = exclusive_diarization.rename_labels(mapping=names)
+        diarization.uri = exclusive_diarization.uri = file["uri"]
+        marks.append(("annotation", time.perf_counter()))
+        # wall-clock per stage of the last finished file (host clock, no device synchronisation)
         self.timings = {b[0]: b[1] - a[1] for a, b in zip(marks[:-1], marks[1:])}
 
-        if centroids is None:
-            output = DiarizeOutput(speaker_diarization=diarization,
-                                   exclusive_speaker_diarization=exclusive_diarization,
-                                   speaker_embeddings=centroids)
-            return output.speaker_diarization if self.legacy else output
-
-        if len(diarization.labels()) > centroids.shape[0]:
-            centroids = np.pad(centroids,
-                               ((0, len(diarization.labels()) - centroids.shape[0]), (0, 0)))
-        inverse_mapping = {label: index for index, label in mapping.items()}
-        centroids = centroids[[inverse_mapping[label] for label in diarization.labels()]]
+        if centroids is not None:
+            if len(labels) > centroids.shape[0]:                                     # (:763-766)
+                centroids = np.pad(centroids, ((0, len(labels) - centroids.shape[0]), (0, 0)))
+            # row order = sorted SPEAKER_xx names (:770-773)
+            cluster_of = {name: label for label, name in names.items()}
+            centroids = centroids[[cluster_of[name] for name in diarization.labels()]]
         output = DiarizeOutput(speaker_diarization=diarization,
                                exclusive_speaker_diarization=exclusive_diarization,
+                               speaker_embeddings=centroids)
+        return output.speaker_diarization if self.legacy else output
+
+    def _speaker_bounds(self, num_speakers, min_speakers, max_speakers, kwargs):
+        if len(kwargs) > 0:
+            warnings.warn(f"Ignoring unexpected keyword arguments: {', '.join(list(kwargs.keys()))}")
+        num_speakers, min_speakers, max_speakers = set_num_speakers(
+            num_speakers=num_speakers, min_speakers=min_speakers, max_speakers=max_speakers)
+        if self._expects_num_speakers and num_speakers is None:
+            raise ValueError(f"num_speakers must be provided when using {self.klustering} clustering")
+        return num_speakers, min_speakers, max_speakers
+
+    # ---------------------------------------------------------------------------------------- apply
+    def apply(self, file: AudioFile, num_speakers: Optional[int] = None,
+              min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
+              hook: Optional[Callable] = None, **kwargs):
+        """speaker_diarization.py:530-784"""
+        num_speakers, min_speakers, max_speakers = self._speaker_bounds(num_speakers, min_speakers,
+                                                                        max_speakers, kwargs)
+        hook = self.setup_hook(file, hook=hook)
+        self._require_device()
+        front = self._front_end(file, hook)
+        if front.silent:
+            return self._empty_output(file)
+        hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
+        return self._back_end(front, hard, centroids, min_speakers, max_speakers, hook)
+
+    def apply_batch(self, files: Iterable[AudioFile], num_speakers: Optional[int] = None,
+                    min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
+                    hook: Optional[Callable] = None, joint_clustering: bool = False,
+                    **kwargs) -> Iterator[Tuple[AudioFile, Any]]:
+        """Several files (core/pipeline.py:489-508 calls this for list inputs) -> (file, output) pairs
+        in input order.
+
+        Default: per-file results identical to `apply`, software-pipelined -- clustering and the back
+        end of file i run on a second stream while the front end of file i+1 runs on the first; one CU
+        is kept free of the persistent convolution kernels for the dendrogram merge.
+        `joint_clustering=True`: ONE clustering over the embeddings of all files (of all ranks when
+        torch.distributed is initialised and `parallel.set_shard` was not used to split single files):
+        speakers get the same label in every file (BASELINE.json configs[4])."""
+        bounds = self._speaker_bounds(num_speakers, min_speakers, max_speakers, kwargs)
+        device = self._require_device()
+        files = [Audio.validate_file(f) for f in files]
+        if joint_clustering:
+            yield from self._apply_jointly(files, bounds, hook, device)
+            return
+        num_speakers, min_speakers, max_speakers = bounds
+        side = torch.cuda.Stream(device=device)
+        lib = ffi.load()
+
+        def tail(front: _FrontEnd, file_hook: Callable):
+            if front.silent:
+                return self._empty_output(front.file)
+            with torch.cuda.device(device), torch.cuda.stream(side):
+                hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
+                out = self._back_end(front, hard, centroids, min_speakers, max_speakers, file_hook)
+                side.synchronize()
+            return out
+
+        lib.pa_set_reserved_cus(1)
+        try:
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                in_flight = None
+                for file in files:
+                    file_hook = self.setup_hook(file, hook=hook)
+                    front = self._front_end(file, file_hook)
+                    if in_flight is not None:
+                        yield in_flight[0], in_flight[1].result()
+                    in_flight = (file, pool.submit(tail, front, file_hook))
+                if in_flight is not None:
+                    yield in_flight[0], in_flight[1].result()
+        finally:
+            lib.pa_set_reserved_cus(0)
+
+    def _apply_jointly(self, files: List[dict], bounds, hook, device: torch.device):
+        """front end per file; records of all files of all ranks gathered on the device; ONE clustering
+        over the concatenation along the chunk axis (oracle: the same clustering called on the
+        concatenated arrays); back end for the local files."""
+        num_speakers, min_speakers, max_speakers = bounds
+        hooks = [self.setup_hook(f, hook=hook) for f in files]
+        fronts = [self._front_end(f, h) for f, h in zip(files, hooks)]
+        voiced = [fr for fr in fronts if not fr.silent]
+        shard = parallel.shard_from_env() if parallel.current_shard().world_size == 1 else parallel.Shard()
+        if not voiced and shard.world_size == 1:
+            for fr in fronts:
+                yield fr.file, self._empty_output(fr.file)
+            return
+        F, S = (voiced[0].dev_seg.shape[1:] if voiced else (0, 0))
+        D = self._embedding.dimension
+        if shard.world_size > 1:
+            records = [parallel.pack_records(fr.dev_seg, fr.dev_emb) for fr in voiced]
+            # (F, S) travel implicitly: all ranks run the same models
+            gathered = parallel.all_gather_files(records, shard, device)
+            if not F:
+                raise RuntimeError("joint clustering: this rank has no voiced file to infer shapes from")
+            segs, embs, owner = [], [], []
+            for r, per_rank in enumerate(gathered):
+                for j, rec in enumerate(per_rank):
+                    seg, emb = parallel.unpack_records(rec, F, S, D)
+                    segs.append(seg.contiguous())
+                    embs.append(emb)
+                    owner.append((r, j))
+            mine = [owner.index((shard.rank, j)) for j in range(len(voiced))]
+        else:
+            segs = [fr.dev_seg for fr in voiced]
+            embs = [fr.dev_emb for fr in voiced]
+            mine = list(range(len(voiced)))
+        sizes = [s.shape[0] for s in segs]
+        all_seg = torch.cat(segs, dim=0).contiguous()
+        all_emb = torch.cat(embs, dim=0).cpu().numpy()
+        _, clean = frame_ops.chunk_stats(all_seg)
+        # the clustering only reads the SHAPE of the segmentations when the clean-frame counts are given
+        seg_view = SlidingWindowFeature(all_seg.cpu().numpy(), self._chunk_grid())
+        hard, _, centroids = self.clustering(
+            embeddings=all_emb, segmentations=seg_view, num_clusters=num_speakers,
+            min_clusters=min_speakers, max_clusters=max_speakers, frames=self._frames,
+            num_clean_frames=clean.cpu().numpy())
+        offsets = np.concatenate([[0], np.cumsum(sizes)])
+        self.joint_hard_clusters = hard                # (sum C, S): kept for inspection / tests
+        self.joint_sizes = sizes
+        k = 0
+        for fr, h in zip(fronts, hooks):
+            if fr.silent:
+                yield fr.file, self._empty_output(fr.file)
+                continue
+            a = offsets[mine[k]]
+            k += 1
+            yield fr.file, self._back_end_joint(fr, hard[a:a + fr.dev_seg.shape[0]].copy(), centroids,
+                                                min_speakers, max_speakers, h)
+
+    def _back_end_joint(self, front, hard, centroids, min_speakers, max_speakers, hook):
+        """joint labels: SPEAKER_k = global cluster k in every file (no per-file renumbering)."""
+        hard = np.where(front.active == 0, -2, hard)
+        capped = np.minimum(front.count.data, max_speakers).astype(np.int8)
+        rec = frame_ops.Reconstructor(front.dev_seg, front.chunks, self._frames, hard, capped)
+        regular = rec.discretize()
+        hook("discrete_diarization", regular)
+        exclusive = rec.discretize(cap=1)
+        gap = self.segmentation.min_duration_off
+        names = {k: f"SPEAKER_{k:02d}" for k in range(max(regular.data.shape[1], 1))}
+        out = []
+        for d in (regular, exclusive):
+            ann = to_annotation(d, min_duration_on=0.0, min_duration_off=gap).rename_labels(mapping=names)
+            ann.uri = front.file["uri"]
+            out.append(ann)
+        output = DiarizeOutput(speaker_diarization=out[0], exclusive_speaker_diarization=out[1],
                                speaker_embeddings=centroids)
         return output.speaker_diarization if self.legacy else output

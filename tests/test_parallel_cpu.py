@@ -32,8 +32,27 @@ def _worker(rank, world, port, total, q):
     shard = parallel.shard_from_env()
     assert (shard.rank, shard.world_size) == (rank, world)
     b, e = parallel.chunk_range(total, shard)
-    s_all, e_all = parallel.all_gather_chunks(seg[b:e], emb[b:e], total, shard, torch.device("cpu"))
-    ok = np.array_equal(s_all, seg) and np.array_equal(e_all, emb, equal_nan=True)
+    s_all, e_all = parallel.all_gather_chunks(torch.from_numpy(seg[b:e]), torch.from_numpy(emb[b:e]), total,
+                                              shard, torch.device("cpu"))
+    assert isinstance(s_all, torch.Tensor) and s_all.dtype == torch.uint8 and e_all.dtype == torch.float32
+    ok = np.array_equal(s_all.numpy(), seg.astype(np.uint8)) and \
+        np.array_equal(e_all.numpy(), emb, equal_nan=True)
+    # multi-file exchange (configs[4]): rank 0 contributes 2 files, rank 1 one, different lengths
+    lens = [[5, 2], [7]]
+    files = [(rng.uniform(size=(c, 37, 3)) < 0.4, rng.standard_normal((c, 3, 16)).astype(np.float32))
+             for per in lens for c in per]
+    first = sum(len(per) for per in lens[:rank])
+    mine = files[first:first + len(lens[rank])]
+    recs = [parallel.pack_records(torch.from_numpy(sg), torch.from_numpy(em)) for sg, em in mine]
+    everything = parallel.all_gather_files(recs, shard, torch.device("cpu"))
+    k = 0
+    for r, per in enumerate(everything):
+        assert len(per) == len(lens[r])
+        for rec in per:
+            sg, em = parallel.unpack_records(rec, 37, 3, 16)
+            ok = ok and np.array_equal(sg.numpy(), files[k][0].astype(np.uint8)) \
+                and np.array_equal(em.numpy(), files[k][1])
+            k += 1
     q.put((rank, b, e, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
