@@ -42,8 +42,10 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec
 MFMA_KERNELS = {"k_conv3x3", "k_conv3x3_wino", "k_gemm_tn", "k_lstm_rec", "k_sinc_fir_pool", "k_conv5_pool"}
 # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and (cin, cout) pair instead of 36
 EXECUTED_FLOP_FRACTION = {"k_conv3x3_wino": 16.0 / 36.0}
-# bare f32-MFMA stream measured on this chip with random operands (tools/probes/pingpong_probe.py)
-SUSTAINED_MFMA_F32_TFLOPS = 132.8
+# bare v_mfma_f32_16x16x4_f32 stream measured on MI355X with random operands over 0.7 s: 151.8 TFLOP/s at
+# a 2.37 GHz shader clock (profiles/r2_clock_trace.txt; bursts of a few ms run at ~2.1 GHz while the
+# clock ramps: profiles/r2_mfma_probe_box2.txt)
+SUSTAINED_MFMA_F32_TFLOPS = 151.8
 
 
 def build_checkpoints(workdir: str):
@@ -189,8 +191,6 @@ def roofline_entry(name: str, r: dict) -> dict:
                                 "note": "flops of the reference operation (direct 3x3 convolution)"},
                 "executed_gflop_per_launch": round(
                     r["flops"] * EXECUTED_FLOP_FRACTION.get(name, 1.0) / launches / 1e9, 3),
-                # bare v_mfma_f32_16x16x4_f32 stream on this chip: 132.8 TFLOP/s on random data (the
-                # chip clocks 2.07 GHz under that load), 149 on zeros (profiles/r2_mfma_probe.txt)
                 "sustained_mfma_tflops": SUSTAINED_MFMA_F32_TFLOPS,
                 "frac_of_sustained": round(executed / SUSTAINED_MFMA_F32_TFLOPS, 4)}
     else:

@@ -220,6 +220,20 @@ int pa_cluster_activations(const uint8_t* seg, int C, int F, int S, const int32_
 int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
                      uint8_t* tie, void* stream);
 
+/* ---- VBx clustering + PLDA (pipelines/clustering.py:550-669, utils/vbx.py:27-218, core/plda.py:33-60) ---- */
+
+/* x-vector -> PLDA space, replaces PLDA.__call__ (core/plda.py:47-60) = plda_tf(xvec_tf(x))
+ * (utils/vbx.py:205-217): X (n, din) fp32 -> fea (n, dout) fp64.  lda [din][dmid], trT [dmid][dout]. */
+int pa_plda_transform(const float* X, int n, int din, int dmid, int dout, const double* mean1,
+                      const double* lda, const double* mean2, const double* mu, const double* trT,
+                      double* fea, void* stream);
+size_t pa_vbx_workspace_bytes(int n, int s, int d);
+/* one iteration of VBx (utils/vbx.py:106-133): M step (16)(17), E step (23) + GMM responsibilities,
+ * ELBO (25) -> elbo_out[0].  gamma (n, s) fp64 is updated in place. */
+int pa_vbx_iteration(const double* fea, const double* Phi, int n, int s, int d, double Fa, double Fb,
+                     int first, double* gamma, double* elbo_out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

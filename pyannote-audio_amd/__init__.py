@@ -10,6 +10,7 @@ from .audio import Audio  # noqa: E402,F401
 from .model import Model, PyanNet, WeSpeakerResNet34, Specifications, Problem, Resolution  # noqa: E402,F401
 from .pipeline import Pipeline  # noqa: E402,F401
 from .inference import Inference  # noqa: E402,F401
-from .agglomerative import AgglomerativeClustering, Clustering  # noqa: E402,F401
+from .clustering import AgglomerativeClustering, Clustering, KMeansClustering, VBxClustering
+from .plda import PLDA  # noqa: E402,F401
 from .speaker_verification import PretrainedSpeakerEmbedding  # noqa: E402,F401
 from .speaker_diarization import SpeakerDiarization, DiarizeOutput  # noqa: E402,F401

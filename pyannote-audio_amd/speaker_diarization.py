@@ -32,7 +32,7 @@ import torch
 from . import ffi
 from . import frames as frame_ops
 from . import parallel
-from .agglomerative import Clustering
+from .clustering import Clustering
 from .audio import Audio, AudioFile
 from .core import Annotation, SlidingWindow, SlidingWindowFeature
 from .diarization import set_num_speakers, to_annotation

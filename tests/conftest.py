@@ -90,7 +90,7 @@ def write_pipeline_dir(root, seg_model, emb_model, config_extra=None):
                    "segmentation": {"min_duration_off": 0.0}},
     }
     if config_extra:
-        config.update(config_extra)
+        config.update(config_extra)   # (whole top-level sections are replaced)
     with open(os.path.join(root, "config.yaml"), "w") as fp:
         yaml.safe_dump(config, fp)
     return os.path.join(root, "config.yaml")
