@@ -220,6 +220,14 @@ int pa_cluster_activations(const uint8_t* seg, int C, int F, int S, const int32_
 int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
                      uint8_t* tie, void* stream);
 
+/* ---- audio front door (core/io.py:223-265) ---- */
+
+/* Polyphase windowed-sinc resampling, replaces torchaudio.functional.resample in
+ * Audio.downmix_and_resample (core/io.py:258-262): x (n) fp32 -> out (n_out) fp32,
+ * out[q P + p] = sum_k taps[p][k] x[q L - width + k], K = 2 width + L taps per phase, zeros outside x. */
+int pa_resample_poly(const float* x, long n, const float* taps, int L, int P, int K, int width, float* out,
+                     long n_out, void* stream);
+
 /* ---- VBx clustering + PLDA (pipelines/clustering.py:550-669, utils/vbx.py:27-218, core/plda.py:33-60) ---- */
 
 /* x-vector -> PLDA space, replaces PLDA.__call__ (core/plda.py:47-60) = plda_tf(xvec_tf(x))

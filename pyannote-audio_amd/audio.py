@@ -2,8 +2,9 @@
 
 The hot path of SURVEY.md section 8 takes `{"waveform": (channel, time) tensor, "sample_rate": int}`;
 WAV files are read with scipy (no ffmpeg/torchcodec in scope).  Down-mixing is the channel mean
-(io.py:223-265); resampling (torchaudio in the reference) uses scipy's polyphase filter and is a
-convenience outside the parity contract."""
+(io.py:223-265); resampling restates `torchaudio.functional.resample` (windowed-sinc polyphase bank,
+io.py:258-262) with the filter bank evaluated on the host in the waveform's dtype and applied by
+`pa_resample_poly` on the GPU (csrc/resample.hip)."""
 from __future__ import annotations
 
 import math
@@ -18,10 +19,50 @@ from .core import Segment
 AudioFile = Union[str, Path, Mapping]
 
 
+def sinc_resample_bank(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                       rolloff: float = 0.99) -> Tuple[torch.Tensor, int, int, int]:
+    """filter bank of torchaudio's "sinc_interp_hann" resampler for orig -> new (reduced by their gcd):
+    (taps (P, K) float32, L input samples per block, P phases, width); K = 2 width + L.  Evaluated with
+    float32 torch operations in torchaudio's order, so that the taps are the ones the reference uses."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    L, P = int(orig_freq) // g, int(new_freq) // g
+    cutoff = min(L, P) * rolloff
+    width = math.ceil(lowpass_filter_width * L / cutoff)
+    grid = torch.arange(-width, width + L, dtype=torch.float32)[None, :] / L
+    t = torch.arange(0, -P, -1, dtype=torch.float32)[:, None] / P + grid
+    t *= cutoff
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t *= math.pi
+    taps = torch.where(t == 0, torch.tensor(1.0), t.sin() / t)
+    taps *= window * (cutoff / L)
+    return taps.contiguous(), L, P, width
+
+
+def resample_on_device(waveform: torch.Tensor, orig_freq: int, new_freq: int,
+                       device: torch.device) -> torch.Tensor:
+    """(channel, time) fp32 -> (channel, ceil(new * time / orig)) on `device` (core/io.py:258-262)"""
+    from . import ffi
+    taps, L, P, width = sinc_resample_bank(orig_freq, new_freq)
+    lib = ffi.load()
+    x = waveform.to(device, torch.float32).contiguous()
+    n = x.shape[1]
+    n_out = int(math.ceil(P * n / L))
+    out = torch.empty((x.shape[0], n_out), dtype=torch.float32, device=device)
+    tp = taps.to(device)
+    with torch.cuda.device(device):
+        for c in range(x.shape[0]):
+            ffi.check(lib.pa_resample_poly(ffi.ptr(x[c]), n, ffi.ptr(tp), L, P, taps.shape[1], width,
+                                           ffi.ptr(out[c]), n_out, ffi.stream()), "pa_resample_poly")
+    return out
+
+
 class Audio:
-    def __init__(self, sample_rate: Optional[int] = None, mono: Optional[str] = None):
+    def __init__(self, sample_rate: Optional[int] = None, mono: Optional[str] = None,
+                 device: Optional[torch.device] = None):
         self.sample_rate = sample_rate
         self.mono = mono
+        self.device = device      # where resampling runs (set by SpeakerDiarization.to)
 
     @staticmethod
     def validate_file(file: AudioFile) -> Mapping:
@@ -58,11 +99,12 @@ class Audio:
             elif self.mono == "downmix":
                 waveform = waveform.mean(dim=0, keepdim=True)
         if self.sample_rate is not None and self.sample_rate != sample_rate:
-            from scipy.signal import resample_poly
-            g = math.gcd(int(self.sample_rate), int(sample_rate))
-            y = resample_poly(waveform.cpu().numpy().astype(np.float64), self.sample_rate // g,
-                              sample_rate // g, axis=-1)
-            waveform = torch.from_numpy(y.astype(np.float32))
+            device = self.device if self.device is not None else \
+                (waveform.device if waveform.is_cuda else None)
+            if device is None or device.type != "cuda":
+                raise RuntimeError(f"resampling {sample_rate} Hz -> {self.sample_rate} Hz runs on the GPU: "
+                                   "move the pipeline to a GPU first (there is no CPU path)")
+            waveform = resample_on_device(waveform, sample_rate, self.sample_rate, device)
             sample_rate = self.sample_rate
         return waveform, sample_rate
 

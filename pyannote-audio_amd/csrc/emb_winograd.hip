@@ -387,9 +387,16 @@ int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U
   pa::ProfScope prof("k_conv3x3_wino", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
                      4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
-  // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that wastes the fewest rows
-  if (H % 8 == 0 || H > 24) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
-  else if (H % 4 == 0 || H > 12) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that pads the map the least (10 s chunks:
+  // 80/40 rows -> 8 x 32, 20 rows -> 4 x 64, 10 rows x 125 columns -> 2 x 128; the 38-column maps of 3 s
+  // segments would waste 70 % of a 128-wide tile and take 4 x 64 instead); ties go to the taller tile,
+  // whose halo is relatively smaller
+  auto padded = [&](int tr, int tcg) {
+    return (long)pa::cdiv(H, 2 * tr) * 2 * tr * (long)pa::cdiv(W, 32 * tcg) * 32 * tcg;
+  };
+  const long a41 = padded(4, 1), a22 = padded(2, 2), a14 = padded(1, 4);
+  if (a41 <= a22 && a41 <= a14) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  else if (a22 <= a14) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   else pa::launch_wino<1, 4>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   PA_CHECK_LAUNCH("pa_conv3x3_wino");
   return 0;

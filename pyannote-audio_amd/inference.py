@@ -124,7 +124,7 @@ class Inference(BaseInference):
         return n, bool(has_last)
 
     def __call__(self, file: AudioFile, hook: Optional[Callable] = None):
-        waveform, sample_rate = Audio(self.model.audio.sample_rate, mono="downmix")(file)
+        waveform, sample_rate = Audio(self.model.audio.sample_rate, mono="downmix", device=self.device)(file)
         if self.window == "sliding":
             return self.slide(waveform, sample_rate, hook=hook)
         out = self.model(waveform[None].to(self.model.device))

@@ -127,6 +127,12 @@ class SpeakerDiarization(Pipeline):
             kwargs["plda"] = self.plda
         return kwargs
 
+    def to(self, device: torch.device):
+        super().to(device)
+        if hasattr(self, "_audio"):
+            self._audio.device = device      # the front door resamples on the pipeline's GPU
+        return self
+
     @property
     def segmentation_batch_size(self) -> int:
         return self._segmentation.batch_size
