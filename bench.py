@@ -188,7 +188,7 @@ def roofline_entry(name: str, r: dict) -> dict:
                 "frac": round(executed / PEAK_MFMA_F32_TFLOPS, 4),
                 "algorithmic": {"tflops": round(algorithmic, 2),
                                 "gflop_per_launch": round(r["flops"] / launches / 1e9, 3),
-                                "note": "flops of the reference operation (direct 3x3 convolution)"},
+                                "note": "flops of the reference operation (for the Winograd kernel: the direct 3x3 convolution)"},
                 "executed_gflop_per_launch": round(
                     r["flops"] * EXECUTED_FLOP_FRACTION.get(name, 1.0) / launches / 1e9, 3),
                 "sustained_mfma_tflops": SUSTAINED_MFMA_F32_TFLOPS,
