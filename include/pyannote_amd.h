@@ -220,6 +220,14 @@ int pa_cluster_activations(const uint8_t* seg, int C, int F, int S, const int32_
 int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
                      uint8_t* tie, void* stream);
 
+/* General overlap-add aggregation, replaces Inference.aggregate (core/inference.py:498-620):
+ * scores (C,F,K) fp32 (NaN = missing), window (F) fp64 = Hamming or ones, warm (F) fp64 = warm-up
+ * window, start_frame (C) non-decreasing -> out (T,K) fp32 = sum / max(weight sum, epsilon) (or the plain sum), `missing` where
+ * nothing voted.  Bit-identical to the reference's chunk loop (same accumulation order and dtypes). */
+int pa_aggregate(const float* scores, int C, int F, int K, const int32_t* start_frame, int T,
+                 const double* window, const double* warm, float epsilon, float missing, int skip_average,
+                 float* out, void* stream);
+
 /* ---- audio front door (core/io.py:223-265) ---- */
 
 /* Polyphase windowed-sinc resampling, replaces torchaudio.functional.resample in

@@ -14,3 +14,4 @@ from .clustering import AgglomerativeClustering, Clustering, KMeansClustering, V
 from .plda import PLDA  # noqa: E402,F401
 from .speaker_verification import PretrainedSpeakerEmbedding  # noqa: E402,F401
 from .speaker_diarization import SpeakerDiarization, DiarizeOutput  # noqa: E402,F401
+from .voice_activity_detection import VoiceActivityDetection  # noqa: E402,F401

@@ -238,3 +238,61 @@ int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// General overlap-add aggregation (core/inference.py:498-620): float scores (NaN = missing), a
+// per-frame weight (Hamming x warm-up), average or plain sum.  Gather form: one thread per (global
+// frame t, class k) walks the chunks that cover t in ASCENDING chunk order and accumulates exactly like
+// the reference's chunk loop does -- float32 accumulators, each addition performed in float64 and
+// rounded back (numpy's `float32_array += float64_array`) -- so the result is bit-identical to it.
+// ---------------------------------------------------------------------------------------------
+namespace pa {
+
+__global__ __launch_bounds__(256) void k_aggregate(const float* __restrict__ scores, int C, int F, int K,
+                                                   const int* __restrict__ start, int T,
+                                                   const double* __restrict__ window,
+                                                   const double* __restrict__ warm, float epsilon,
+                                                   float missing, int skip_average,
+                                                   float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)T * K) return;
+  const int t = (int)(idx / K), k = (int)(idx % K);
+  // first chunk c with start[c] + F > t (start is non-decreasing)
+  int lo = 0, hi = C;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (start[mid] + F > t) hi = mid;
+    else lo = mid + 1;
+  }
+  float agg = 0.f, cnt = 0.f, msk = 0.f;
+  for (int c = lo; c < C && start[c] <= t; ++c) {
+    const int f = t - start[c];
+    const float x = scores[((long)c * F + f) * K + k];
+    const bool nan = x != x;
+    const double m = nan ? 0.0 : 1.0;
+    // ((score * mask) * hamming) * warm_up and ((mask * hamming) * warm_up), as numpy evaluates them
+    agg = (float)((double)agg + (((double)(nan ? 0.f : x) * m) * window[f]) * warm[f]);
+    cnt = (float)((double)cnt + (m * window[f]) * warm[f]);
+    msk = fmaxf(msk, nan ? 0.f : 1.f);
+  }
+  float v = skip_average ? agg : agg / fmaxf(cnt, epsilon);
+  if (msk == 0.f) v = missing;
+  out[idx] = v;
+}
+
+}  // namespace pa
+
+extern "C" {
+
+int pa_aggregate(const float* scores, int C, int F, int K, const int32_t* start_frame, int T,
+                 const double* window, const double* warm, float epsilon, float missing, int skip_average,
+                 float* out, void* stream) {
+  if (T <= 0 || K <= 0) return 0;
+  pa::ProfScope prof("k_aggregate", stream, 3.0 * C * (double)F * K, 4.0 * ((double)C * F * K + (double)T * K));
+  hipLaunchKernelGGL(pa::k_aggregate, dim3(pa::cdiv((long)T * K, 256)), dim3(256), 0, (hipStream_t)stream,
+                     scores, C, F, K, start_frame, T, window, warm, epsilon, missing, skip_average, out);
+  PA_CHECK_LAUNCH("pa_aggregate");
+  return 0;
+}
+
+}  // extern "C"

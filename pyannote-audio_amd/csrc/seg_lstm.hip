@@ -142,7 +142,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 // ---------------------------------------------------------------------------------------------
 constexpr int LSTM_HS = 162;  // LDS row stride of h (floats); k index j lives at (j/32)*33 + j%32
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware exp / rcp units: v_exp_f32 and v_rcp_f32 are accurate to ~1 ulp
+// each, far inside the float contract of the path (the end-to-end log-probabilities sit at 0.002 of the
+// rtol 1e-4 / atol 1e-5 bound, tests/test_seg_gpu.py), and the f32 MFMA shares the vector ALUs with
+// these instructions: libm's expf / tanhf cost ~5x the issue cycles per step.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 2 sigmoid(2x) - 1; the argument is clamped so that exp2 stays finite
+  const float xc = fminf(fmaxf(x, -15.f), 15.f);
+  return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * xc)) - 1.0f;
+}
 
 __global__ __launch_bounds__(256, 1) void k_lstm_rec(const float* __restrict__ xproj,
                                                       const float* __restrict__ whh_p,
@@ -208,11 +219,11 @@ __global__ __launch_bounds__(256, 1) void k_lstm_rec(const float* __restrict__ x
       for (int r = 0; r < 4; ++r) {
         const float ig = sigmoidf_(acc[0 + s][r]);
         const float fg = sigmoidf_(acc[2 + s][r]);
-        const float gg = tanhf(acc[4 + s][r]);
+        const float gg = tanhf_(acc[4 + s][r]);
         const float og = sigmoidf_(acc[6 + s][r]);
         const float cn = fg * c[s][r] + ig * gg;
         c[s][r] = cn;
-        const float h = og * tanhf(cn);
+        const float h = og * tanhf_(cn);
         hn[r * LSTM_HS + 16 * s] = h;
         op[r * 256 + 16 * s] = h;
       }

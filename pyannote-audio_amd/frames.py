@@ -73,6 +73,31 @@ def speaker_count(seg: torch.Tensor, chunks: SlidingWindow, frames: SlidingWindo
     return SlidingWindowFeature(count.cpu().numpy().reshape(T, 1), out_frames)
 
 
+def aggregate(scores, chunks: SlidingWindow, frames: SlidingWindow, device: torch.device,
+              warm_up: Tuple[float, float] = (0.0, 0.0), epsilon: float = 1e-12, hamming: bool = False,
+              missing: float = np.nan, skip_average: bool = False) -> SlidingWindowFeature:
+    """`Inference.aggregate` (core/inference.py:498-620) on the GPU: scores (C, F, K) host array or device
+    tensor -> SlidingWindowFeature (T, K) float32, bit-identical to the reference's chunk loop."""
+    x = torch.as_tensor(scores).to(device=device, dtype=torch.float32).contiguous()
+    C, F, K = x.shape
+    starts, T, out_frames = frame_geometry(chunks, frames, C)
+    window = np.hamming(F) if hamming else np.ones(F)
+    warm = np.ones(F)
+    left = round(warm_up[0] / chunks.duration * F)
+    right = round(warm_up[1] / chunks.duration * F)
+    warm[:left] = epsilon
+    warm[F - right:] = epsilon
+    with torch.cuda.device(device):
+        w = torch.from_numpy(np.ascontiguousarray(window, dtype=np.float64)).to(device)
+        wu = torch.from_numpy(warm).to(device)
+        st = torch.from_numpy(starts).to(device)
+        out = torch.empty((T, K), dtype=torch.float32, device=device)
+        ffi.check(ffi.load().pa_aggregate(ffi.ptr(x), C, F, K, ffi.ptr(st), T, ffi.ptr(w), ffi.ptr(wu), float(epsilon),
+                                          float(missing), int(skip_average), ffi.ptr(out), ffi.stream()),
+                  "pa_aggregate")
+    return SlidingWindowFeature(out.cpu().numpy(), out_frames)
+
+
 class Reconstructor:
     """speaker_diarization.py:480-528 + diarization.py:221-268: cluster activations are accumulated
     once, then discretised for any per-frame cap (regular and exclusive diarization share them)."""

@@ -108,10 +108,11 @@ class Inference(BaseInference):
 
         if self.pre_aggregation_hook is not None:
             outputs = self.pre_aggregation_hook(outputs)
-        aggregated = self.aggregate(
-            SlidingWindowFeature(outputs, SlidingWindow(start=0.0, duration=self.duration,
-                                                        step=self.step)),
-            frames, warm_up=self.warm_up, hamming=True, missing=0.0)
+        # Hamming-weighted overlap-add on the GPU (pa_aggregate), bit-identical to `self.aggregate`
+        from . import frames as frame_ops
+        aggregated = frame_ops.aggregate(
+            outputs, SlidingWindow(start=0.0, duration=self.duration, step=self.step), frames,
+            self.model.device, warm_up=self.warm_up, hamming=True, missing=0.0)
         if has_last_chunk:
             aggregated.data = aggregated.crop(Segment(0.0, num_samples / sample_rate), mode="loose")
         return aggregated

@@ -73,6 +73,9 @@ def get_class_by_name(class_name: str, default_module_name: Optional[str] = None
     if class_name.startswith("pyannote.audio.pipelines") and tokens[-1] == "SpeakerDiarization":
         from .speaker_diarization import SpeakerDiarization
         return SpeakerDiarization
+    if class_name.startswith("pyannote.audio.pipelines") and tokens[-1] == "VoiceActivityDetection":
+        from .voice_activity_detection import VoiceActivityDetection
+        return VoiceActivityDetection
     if len(tokens) == 1:
         if default_module_name is None:
             raise ValueError(f"cannot resolve class {class_name!r} without a module name")
