@@ -99,6 +99,9 @@ int pa_conv5_pool(const float* xin, int B, int cin, int Lin, const float* in_mea
                   const float* bias64, float* out, void* stream);
 int pa_norm_transpose(const float* xin, int B, int T, const float* in_mean, const float* in_rstd,
                       const float* gam, const float* bet, float* X0, void* stream);
+/* + act 2 = ReLU and an optional residual laid out like C (out_mode 0): C = act(A W^T + bias + Res) */
+int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
+                  float* C, long ldc, int M, int N, int K, int act, int out_mode, void* stream);
 int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, long ldc,
                int M, int N, int K, int act, int out_mode, void* stream);
 int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T,
@@ -115,14 +118,15 @@ int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, cons
  * The backbone runs once per chunk and is pooled for all S masks (forward_frames /
  * forward_embedding split, wespeaker/__init__.py:288-322).
  * ---------------------------------------------------------------------------------------- */
-#define PA_MAX_RES_BLOCKS 64
+#define PA_MAX_RES_BLOCKS 128   /* ResNet293: 10 + 20 + 64 + 3 = 97 blocks */
 
 typedef struct pa_emb_weights {
   int32_t num_mel;       /* 80 */
   int32_t embed_dim;     /* 256 */
   int32_t num_layers;    /* 4 */
-  int32_t num_blocks[4]; /* 3,4,6,3 */
+  int32_t num_blocks[4]; /* 3,4,6,3 (ResNet34); 3,8,36,3 / 6,16,48,3 / 10,20,64,3 (ResNet152/221/293) */
   int32_t planes[4];     /* 32,64,128,256 */
+  int32_t bottleneck;    /* 0: BasicBlock (resnet.py:84-145); 1: Bottleneck, expansion 4 (resnet.py:148-212) */
   /* fbank tables */
   const float* fb_window;   /* [400] hamming (periodic=False) */
   const float* fb_tw256;    /* [256][2] exp(-2 pi i m/256) */
@@ -139,9 +143,12 @@ typedef struct pa_emb_weights {
   const float* blk_shift2[PA_MAX_RES_BLOCKS];
   const float* blk_u1[PA_MAX_RES_BLOCKS];     /* [16][cout][cin] Winograd F(2x2,3x3) image G g G^T of w1, or NULL */
   const float* blk_u2[PA_MAX_RES_BLOCKS];     /* same for w2; used for stride-1 convolutions when not NULL */
-  const float* blk_wsc[PA_MAX_RES_BLOCKS];    /* [cout][cin] 1x1 stride-2 shortcut or NULL */
+  const float* blk_wsc[PA_MAX_RES_BLOCKS];    /* [cout][cin] 1x1 shortcut (stride 2, or stride 1 for the first Bottleneck) or NULL */
   const float* blk_shiftsc[PA_MAX_RES_BLOCKS];
-  const float* seg1_w; /* [embed_dim][2 * planes[3] * num_mel/8] */
+  /* Bottleneck only: w1 = [planes][cin] 1x1, w2 / u2 = the 3x3 (stride s), w3 = [4 planes][planes] 1x1 */
+  const float* blk_w3[PA_MAX_RES_BLOCKS];
+  const float* blk_shift3[PA_MAX_RES_BLOCKS];
+  const float* seg1_w; /* [embed_dim][2 * expansion * planes[3] * num_mel/8] */
   const float* seg1_b;
 } pa_emb_weights;
 

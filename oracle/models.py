@@ -360,9 +360,36 @@ class BasicBlock(nn.Module):
         return F.relu(out)
 
 
-class ResNet(nn.Module):
-    def __init__(self, num_blocks=(3, 4, 6, 3), m_channels=32, feat_dim=80, embed_dim=256):
+class Bottleneck(nn.Module):
+    """wespeaker/resnet.py:148-212 (ResNet50/101/152/221/293)"""
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1):
         super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, self.expansion * planes, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(self.expansion * planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != self.expansion * planes:
+            self.shortcut = nn.Sequential(
+                nn.Conv2d(in_planes, self.expansion * planes, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(self.expansion * planes))
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        out = out + self.shortcut(x)
+        return F.relu(out)
+
+
+class ResNet(nn.Module):
+    def __init__(self, num_blocks=(3, 4, 6, 3), m_channels=32, feat_dim=80, embed_dim=256, block=None):
+        super().__init__()
+        self.block = block or BasicBlock
         self.in_planes = m_channels
         self.stats_dim = int(feat_dim / 8) * m_channels * 8
         self.conv1 = nn.Conv2d(1, m_channels, 3, stride=1, padding=1, bias=False)
@@ -372,13 +399,13 @@ class ResNet(nn.Module):
         self.layer3 = self._make_layer(m_channels * 4, num_blocks[2], 2)
         self.layer4 = self._make_layer(m_channels * 8, num_blocks[3], 2)
         self.pool = TSTP()
-        self.seg_1 = nn.Linear(self.stats_dim * 2, embed_dim)
+        self.seg_1 = nn.Linear(self.stats_dim * self.block.expansion * 2, embed_dim)
 
     def _make_layer(self, planes, n, stride):
         layers = []
         for s in [stride] + [1] * (n - 1):
-            layers.append(BasicBlock(self.in_planes, planes, s))
-            self.in_planes = planes
+            layers.append(self.block(self.in_planes, planes, s))
+            self.in_planes = planes * self.block.expansion
         return nn.Sequential(*layers)
 
     def forward_frames(self, fbank):
@@ -399,13 +426,16 @@ class ResNet(nn.Module):
 class WeSpeakerResNet34(nn.Module):
     """fbank -> ResNet34 -> TSTP -> Linear(5120, 256)  (wespeaker/__init__.py:324-372)."""
 
-    def __init__(self, sample_rate=16000, num_mel_bins=80, frame_length=25, frame_shift=10):
+    def __init__(self, sample_rate=16000, num_mel_bins=80, frame_length=25, frame_shift=10,
+                 num_blocks=(3, 4, 6, 3), block=None):
         super().__init__()
         self.sample_rate = sample_rate
         self.num_mel_bins = num_mel_bins
         self.frame_length = frame_length
         self.frame_shift = frame_shift
-        self.resnet = ResNet((3, 4, 6, 3), 32, num_mel_bins, 256)
+        # block=Bottleneck with (3, 8, 36, 3) / (6, 16, 48, 3) / (10, 20, 64, 3) = WeSpeakerResNet152 /
+        # 221 / 293 (wespeaker/__init__.py:375-470, resnet.py:477-507)
+        self.resnet = ResNet(num_blocks, 32, num_mel_bins, 256, block=block)
 
     def compute_fbank(self, waveforms):
         waveforms = waveforms * (1 << 15)

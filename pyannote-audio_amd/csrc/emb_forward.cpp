@@ -14,7 +14,7 @@ namespace {
 struct EmbPlan {
   int B, N, T, F, S;
   int Hs[5], Ws[5];  // spatial dims after stem (index 0) and after each layer
-  size_t fbank, act[3], stats, total, act_elems;
+  size_t fbank, act[4], stats, total, act_elems;
 };
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
@@ -39,10 +39,14 @@ bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p) {
     return r;
   };
   p->fbank = take((size_t)B * p->T * p->F);
-  p->act_elems = (size_t)B * p->Hs[0] * p->Ws[0] * w->planes[0];
-  for (int i = 0; i < 3; ++i) p->act[i] = take(p->act_elems);
+  // largest activation: the output of layer 1 (Hs[0] x Ws[0] pixels, planes[0] x expansion channels)
+  const int ex = w->bottleneck ? 4 : 1;
+  p->act_elems = (size_t)B * p->Hs[0] * p->Ws[0] * w->planes[0] * ex;
+  // BasicBlock: 3 ping-pong buffers; Bottleneck: block input / output / shortcut at 4 x planes channels
+  // (3 buffers) + the two planes-wide intermediates and the stride-2 gather (a 4th buffer, split in 3)
+  for (int i = 0; i < (w->bottleneck ? 4 : 3); ++i) p->act[i] = take(p->act_elems);
   const int L = w->num_layers;
-  p->stats = take((size_t)B * p->S * 2 * w->planes[L - 1] * p->Hs[L]);
+  p->stats = take((size_t)B * p->S * 2 * w->planes[L - 1] * ex * p->Hs[L]);
   p->total = o;
   return true;
 }
@@ -101,6 +105,59 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
 
   int blk = 0;
   int cin = w->planes[0];
+  if (w->bottleneck) {
+    // Bottleneck blocks (resnet.py:148-212): 1x1 (GEMM over the pixels of the NHWC map) -> 3x3 (Winograd /
+    // strided direct kernel) -> 1x1 + shortcut + ReLU fused into the last GEMM's epilogue
+    float* nxt = f1;                 // block output
+    float* sc = f2;                  // shortcut branch
+    // 4th buffer = t1 (<= act_elems / 2: the 1x1 of a stride-2 block runs at the INPUT resolution with
+    // twice the planes) | t2 (<= act_elems / 4) | stride-2 gather (<= act_elems / 4)
+    float* tmp = ws + p.act[3];
+    const size_t quarter = p.act_elems / 4;
+    for (int l = 0; l < w->num_layers; ++l) {
+      const int planes = w->planes[l], cout = 4 * planes;
+      for (int i = 0; i < w->num_blocks[l]; ++i, ++blk) {
+        if (blk >= PA_MAX_RES_BLOCKS) {
+          pa::set_error("pa_emb_forward: more than %d residual blocks", PA_MAX_RES_BLOCKS);
+          return 3;
+        }
+        const int stride = (i == 0 && l > 0) ? 2 : 1;
+        const int H = stride == 2 ? p.Hs[l] : p.Hs[l + 1], W = stride == 2 ? p.Ws[l] : p.Ws[l + 1];
+        const int Ho = p.Hs[l + 1], Wo = p.Ws[l + 1];
+        float* t1 = tmp;
+        float* t2 = tmp + 2 * quarter;
+        float* G = tmp + 3 * quarter;
+        RUN(pa_gemm_tn_ex(cur, cin, w->blk_w1[blk], cin, w->blk_shift1[blk], nullptr, t1, planes, B * H * W,
+                          planes, cin, 2, 0, stream));
+        if (stride == 1 && w->blk_u2[blk] != nullptr)
+          RUN(pa_conv3x3_wino(t1, B, H, W, planes, w->blk_u2[blk], w->blk_shift2[blk], nullptr, t2, planes, 1,
+                              stream));
+        else
+          RUN(pa_conv3x3(t1, B, H, W, planes, w->blk_w2[blk], w->blk_shift2[blk], nullptr, t2, planes, stride,
+                         1, stream));
+        const float* res = cur;      // identity shortcut
+        if (w->blk_wsc[blk] != nullptr) {
+          const float* src = cur;
+          if (stride == 2) {
+            RUN(pa_gather_s2(cur, B, H, W, cin, G, stream));
+            src = G;
+          }
+          RUN(pa_gemm_tn_ex(src, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], nullptr, sc, cout,
+                            B * Ho * Wo, cout, cin, 0, 0, stream));
+          res = sc;
+        } else if (stride != 1 || cin != cout) {
+          pa::set_error("pa_emb_forward: block %d needs a shortcut conv but none was given", blk);
+          return 3;
+        }
+        RUN(pa_gemm_tn_ex(t2, planes, w->blk_w3[blk], planes, w->blk_shift3[blk], res, nxt, cout, B * Ho * Wo,
+                          cout, planes, 2, 0, stream));
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+        cin = cout;
+      }
+    }
+  } else
   for (int l = 0; l < w->num_layers; ++l) {
     const int cout = w->planes[l];
     for (int i = 0; i < w->num_blocks[l]; ++i, ++blk) {
@@ -153,9 +210,9 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
   }
   const int L = w->num_layers;
   const int S = p.S;
-  RUN(pa_stats_pool(cur, B, p.Hs[L], p.Ws[L], w->planes[L - 1], masks, S, mask_frames, nearest_idx,
-                    ws + p.stats, stream));
-  const int D2 = 2 * w->planes[L - 1] * p.Hs[L];
+  const int cfin = w->planes[L - 1] * (w->bottleneck ? 4 : 1);
+  RUN(pa_stats_pool(cur, B, p.Hs[L], p.Ws[L], cfin, masks, S, mask_frames, nearest_idx, ws + p.stats, stream));
+  const int D2 = 2 * cfin * p.Hs[L];
   RUN(pa_gemm_tn(ws + p.stats, D2, w->seg1_w, D2, w->seg1_b, emb, w->embed_dim, B * S, w->embed_dim, D2,
                  0, 0, stream));
 #undef RUN

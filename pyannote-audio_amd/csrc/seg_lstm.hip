@@ -25,10 +25,13 @@ constexpr int GK = 32;       // BK
 constexpr int GLD = GK + 4;  // LDS row stride (floats): 9 x 16-B slots -> conflict-free b128 reads
 
 // out_mode 0: C[m*ldc + n]; out_mode 1 (LSTM gate pre-activations): C[((m>>4)*N + n)*16 + (m&15)]
+// ACT: 0 none, 1 leaky_relu(0.01), 2 relu.  RES (out_mode 0 only): C = act(A W^T + bias + Res), Res laid
+// out like C -- the 1x1 "conv3 + bn3 + shortcut + relu" of a Bottleneck block (resnet.py:205-211).
 template <int ACT, int OUT_MODE>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda,
                                                   const float* __restrict__ W, int ldw,
                                                   const float* __restrict__ bias,
+                                                  const float* __restrict__ Res,
                                                   float* __restrict__ C, long ldc, int M, int N, int K,
                                                   int nm, int nn) {
   __shared__ __attribute__((aligned(16))) float As[GB * GLD];
@@ -116,7 +119,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][j][4 * q + e] + bv;
+          if (OUT_MODE == 0 && Res != nullptr && n < N && m + e < M) v[e] += Res[(long)(m + e) * ldc + n];
           if (ACT == 1) v[e] = leaky_relu(v[e]);
+          if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
         }
         if (n < N) {
           if (OUT_MODE == 0) {
@@ -298,9 +303,18 @@ __global__ __launch_bounds__(256) void k_classifier(const float* __restrict__ X,
 // =============================================================================================
 extern "C" {
 
+int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
+                  float* C, long ldc, int M, int N, int K, int act, int out_mode, void* stream);
+
 int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, long ldc,
                int M, int N, int K, int act, int out_mode, void* stream) {
+  return pa_gemm_tn_ex(A, lda, W, ldw, bias, nullptr, C, ldc, M, N, K, act, out_mode, stream);
+}
+
+int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
+                  float* C, long ldc, int M, int N, int K, int act, int out_mode, void* stream) {
   if (M <= 0 || N <= 0) return 0;
+  PA_REQUIRE(Res == nullptr || out_mode == 0, "pa_gemm_tn_ex: a residual needs out_mode 0");
   PA_REQUIRE(K % pa::GK == 0 && lda % 4 == 0 && ldw % 4 == 0,
              "pa_gemm_tn: K (%d) must be a multiple of 32 and lda/ldw multiples of 4", K);
   PA_REQUIRE(out_mode == 0 || (M % 16 == 0), "pa_gemm_tn: out_mode 1 needs M %% 16 == 0");
@@ -310,9 +324,10 @@ int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bi
   pa::ProfScope prof("k_gemm_tn", stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define PA_GEMM(ACT, OM)                                                                          \
   hipLaunchKernelGGL((pa::k_gemm_tn<ACT, OM>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, \
-                     C, ldc, M, N, K, nm, nn)
+                     Res, C, ldc, M, N, K, nm, nn)
   if (act == 0 && out_mode == 0) PA_GEMM(0, 0);
   else if (act == 1 && out_mode == 0) PA_GEMM(1, 0);
+  else if (act == 2 && out_mode == 0) PA_GEMM(2, 0);
   else if (act == 0 && out_mode == 1) PA_GEMM(0, 1);
   else PA_REQUIRE(false, "pa_gemm_tn: unsupported act/out_mode %d/%d", act, out_mode);
 #undef PA_GEMM

@@ -32,13 +32,13 @@ class SegWeights(C.Structure):
     ]
 
 
-PA_MAX_RES_BLOCKS = 64
+PA_MAX_RES_BLOCKS = 128
 
 
 class EmbWeights(C.Structure):
     _fields_ = [
         ("num_mel", C.c_int32), ("embed_dim", C.c_int32), ("num_layers", C.c_int32),
-        ("num_blocks", C.c_int32 * 4), ("planes", C.c_int32 * 4),
+        ("num_blocks", C.c_int32 * 4), ("planes", C.c_int32 * 4), ("bottleneck", C.c_int32),
         ("fb_window", c_fp), ("fb_tw256", c_fp), ("fb_tw512", c_fp), ("fb_mel_w", c_fp),
         ("fb_mel_lo", c_fp), ("fb_mel_hi", c_fp),
         ("stem_w", c_fp), ("stem_shift", c_fp),
@@ -46,6 +46,7 @@ class EmbWeights(C.Structure):
         ("blk_w2", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift2", c_fp * PA_MAX_RES_BLOCKS),
         ("blk_u1", c_fp * PA_MAX_RES_BLOCKS), ("blk_u2", c_fp * PA_MAX_RES_BLOCKS),
         ("blk_wsc", c_fp * PA_MAX_RES_BLOCKS), ("blk_shiftsc", c_fp * PA_MAX_RES_BLOCKS),
+        ("blk_w3", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift3", c_fp * PA_MAX_RES_BLOCKS),
         ("seg1_w", c_fp), ("seg1_b", c_fp),
     ]
 
@@ -87,6 +88,8 @@ def load():
     lib.pa_conv5_pool.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                   c_fp, c_fp]
     lib.pa_norm_transpose.argtypes = [c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+    lib.pa_gemm_tn_ex.argtypes = [c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, c_fp]
     lib.pa_gemm_tn.argtypes = [c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, c_fp]
     lib.pa_lstm_rec.argtypes = [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]

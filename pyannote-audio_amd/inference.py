@@ -19,41 +19,41 @@ from .pipeline import BaseInference
 
 
 class Inference(BaseInference):
+    """`Inference(model, window="sliding", duration=None, step=None, pre_aggregation_hook=None,
+    skip_aggregation=False, skip_conversion=False, device=None, batch_size=32)` -- the constructor
+    contract of core/inference.py:78-167."""
+
     def __init__(self, model: Model, window: str = "sliding", duration: Optional[float] = None,
                  step: Optional[float] = None, pre_aggregation_hook: Optional[Callable] = None,
                  skip_aggregation: bool = False, skip_conversion: bool = False,
                  device: Optional[torch.device] = None, batch_size: int = 32):
-        self.model = model
-        if device is None:
-            device = self.model.device
-        self.device = device
-        self.model.eval()
-        self.model.to(self.device)
-        specifications = self.model.specifications
-        if window not in ["sliding", "whole"]:
+        if window not in ("sliding", "whole"):
             raise ValueError('`window` must be "sliding" or "whole".')
-        if window == "whole" and specifications.resolution == Resolution.FRAME:
-            warnings.warn('Using "whole" `window` inference with a frame-based model might lead to bad '
-                          'results and huge memory consumption: it is recommended to set `window` to '
-                          '"sliding".')
+        self.model = model
+        self.device = device if device is not None else model.device
+        model.eval()
+        model.to(self.device)
+        spec = model.specifications
         self.window = window
-        training_duration = specifications.duration
-        duration = duration or training_duration
-        if training_duration != duration:
-            warnings.warn(f"Model was trained with {training_duration:g}s chunks, and you requested "
-                          f"{duration:g}s chunks for inference: this might lead to suboptimal results.")
-        self.duration = duration
+        if window == "whole" and spec.resolution == Resolution.FRAME:
+            warnings.warn('"whole"-window inference of a frame-level model processes the entire file as '
+                          'one chunk (memory grows with the file, and the model never saw such lengths): '
+                          'prefer window="sliding".')
+        self.duration = duration or spec.duration
+        if self.duration != spec.duration:
+            warnings.warn(f"chunk duration {self.duration:g}s differs from the {spec.duration:g}s the "
+                          f"model was trained with: expect degraded results.")
+        self.warm_up = spec.warm_up
+        # default hop: 10 % of a chunk, or the left warm-up when the model declares one
+        self.step = step or (self.warm_up[0] if self.warm_up[0] != 0.0 else 0.1 * self.duration)
+        if self.step > self.duration:
+            raise ValueError(
+                f"Step between consecutive chunks is set to {self.step:g}s, while chunks are only "
+                f"{self.duration:g}s long, leading to gaps between consecutive chunks. Either decrease "
+                f"step or increase duration.")
         self.skip_conversion = skip_conversion
         self.skip_aggregation = skip_aggregation
         self.pre_aggregation_hook = pre_aggregation_hook
-        self.warm_up = specifications.warm_up
-        step = step or (0.1 * self.duration if self.warm_up[0] == 0.0 else self.warm_up[0])
-        if step > self.duration:
-            raise ValueError(
-                f"Step between consecutive chunks is set to {step:g}s, while chunks are only "
-                f"{self.duration:g}s long, leading to gaps between consecutive chunks. Either decrease "
-                f"step or increase duration.")
-        self.step = step
         # kept for API compatibility: the engine sizes its own launch groups (see DESIGN.md); the
         # value only sets the granularity at which `hook` is called.
         self.batch_size = batch_size
@@ -180,19 +180,20 @@ class Inference(BaseInference):
     @staticmethod
     def trim(scores: SlidingWindowFeature, warm_up: Tuple[float, float] = (0.1, 0.1)
              ) -> SlidingWindowFeature:
-        """inference.py:622-667"""
-        assert scores.data.ndim == 3
-        _, num_frames, _ = scores.data.shape
-        chunks = scores.sliding_window
-        left = round(num_frames * warm_up[0])
-        right = round(num_frames * warm_up[1])
-        step_frames = round(num_frames * chunks.step / chunks.duration)
-        if num_frames - left - right < step_frames:
-            warnings.warn(f"Total `warm_up` is so large ({sum(warm_up) * 100:g}% of each chunk) that "
-                          f"resulting trimmed scores does not cover a whole step ({chunks.step:g}s)")
-        new_chunks = SlidingWindow(start=chunks.start + warm_up[0] * chunks.duration, step=chunks.step,
-                                   duration=(1 - warm_up[0] - warm_up[1]) * chunks.duration)
-        return SlidingWindowFeature(scores.data[:, left:num_frames - right], new_chunks)
+        """drop the warm-up frames at both ends of every chunk and shrink the chunk grid accordingly
+        (core/inference.py:622-667); `warm_up` are fractions of a chunk."""
+        if scores.data.ndim != 3:
+            raise ValueError("trim expects (chunks, frames, classes) scores")
+        num_frames = scores.data.shape[1]
+        grid = scores.sliding_window
+        lead, tail = warm_up
+        first, last = round(num_frames * lead), num_frames - round(num_frames * tail)
+        if last - first < round(num_frames * grid.step / grid.duration):
+            warnings.warn(f"a warm-up of {100 * (lead + tail):g}% leaves less than one hop "
+                          f"({grid.step:g}s) of every chunk: consecutive chunks no longer overlap")
+        trimmed = SlidingWindow(start=grid.start + lead * grid.duration, step=grid.step,
+                                duration=(1 - lead - tail) * grid.duration)
+        return SlidingWindowFeature(scores.data[:, first:last], trimmed)
 
 
 def aggregate_start_frames(chunks: SlidingWindow, frames: SlidingWindow, num_chunks: int) -> np.ndarray:

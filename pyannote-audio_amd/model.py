@@ -307,10 +307,13 @@ class Model:
             checkpoint = p
         ckpt = load_checkpoint(checkpoint)
         arch = ckpt["pyannote.audio"]["architecture"]["class"]
-        klass = {"PyanNet": PyanNet, "WeSpeakerResNet34": WeSpeakerResNet34}.get(arch)
+        klass = {"PyanNet": PyanNet, "WeSpeakerResNet34": WeSpeakerResNet34,
+                 "WeSpeakerResNet152": WeSpeakerResNet152, "WeSpeakerResNet221": WeSpeakerResNet221,
+                 "WeSpeakerResNet293": WeSpeakerResNet293}.get(arch)
         if klass is None:
             raise NotImplementedError(
-                f"architecture {arch!r} is outside the accelerated hot path (PyanNet, WeSpeakerResNet34)")
+                f"architecture {arch!r} is outside the accelerated hot path (PyanNet, "
+                "WeSpeakerResNet34/152/221/293)")
         return klass(ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {})),
                      ckpt["pyannote.audio"]["specifications"])
 
@@ -365,29 +368,46 @@ class WeSpeakerResNet34(Model):
     def dimension(self) -> int:
         return int(self._state_dict["resnet.seg_1.weight"].shape[0])
 
+    @property
+    def _bottleneck(self) -> bool:
+        return "resnet.layer1.0.conv3.weight" in self._state_dict
+
+    @property
+    def _num_blocks(self):
+        return [1 + max(int(k.split(".")[2]) for k in self._state_dict if k.startswith(f"resnet.layer{l}."))
+                for l in (1, 2, 3, 4)]
+
+    def _conv_chain(self):
+        """(kernel, stride, padding) of every convolution along the time axis: stem, then per block
+        3,3 (BasicBlock, resnet.py:108-133) or 1,3,1 (Bottleneck, :181-203), the block's stride on its
+        first 3x3"""
+        ks, ss, ps = [3], [1], [1]
+        for n, s in zip(self._num_blocks, (1, 2, 2, 2)):
+            for i in range(n):
+                st = s if i == 0 else 1
+                if self._bottleneck:
+                    ks += [1, 3, 1]
+                    ss += [1, st, 1]
+                    ps += [0, 1, 0]
+                else:
+                    ks += [3, 3]
+                    ss += [st, 1]
+                    ps += [1, 1]
+        return ks, ss, ps
+
     def num_frames(self, num_samples: int) -> int:
         t = multi_conv_num_frames(num_samples, [400], [160], [0], [1])
-        for s in (1, 1, 2, 2, 2):  # conv1 + first conv of each layer (3x3, pad 1)
+        for s in (1, 1, 2, 2, 2):  # conv1 + the strided 3x3 of each layer (pad 1)
             t = (t + 2 - 3) // s + 1
         return t
 
     def receptive_field_size(self, num_frames: int = 1) -> int:
-        ks, ss, ps = [3], [1], [1]
-        for n, s in zip((3, 4, 6, 3), (1, 2, 2, 2)):
-            for i in range(n):
-                ks += [3, 3]
-                ss += [s if i == 0 else 1, 1]
-                ps += [1, 1]
+        ks, ss, ps = self._conv_chain()
         size = multi_conv_receptive_field_size(num_frames, ks, ss, ps, [1] * len(ks))
         return multi_conv_receptive_field_size(size, [400], [160], [0], [1])
 
     def receptive_field_center(self, frame: int = 0) -> int:
-        ks, ss, ps = [3], [1], [1]
-        for n, s in zip((3, 4, 6, 3), (1, 2, 2, 2)):
-            for i in range(n):
-                ks += [3, 3]
-                ss += [s if i == 0 else 1, 1]
-                ps += [1, 1]
+        ks, ss, ps = self._conv_chain()
         c = multi_conv_receptive_field_center(frame, ks, ss, ps, [1] * len(ks))
         return multi_conv_receptive_field_center(c, [400], [160], [0], [1])
 
@@ -401,6 +421,20 @@ class WeSpeakerResNet34(Model):
         return self.engine.forward(waveforms, weights)
 
     forward = __call__
+
+
+class WeSpeakerResNet152(WeSpeakerResNet34):
+    """Bottleneck [3, 8, 36, 3] (wespeaker/__init__.py:375-404); depth and block type are read from the
+    state-dict keys, so the three Bottleneck classes only differ by the name the checkpoint carries."""
+    ARCHITECTURE = ("pyannote.audio.models.embedding.wespeaker", "WeSpeakerResNet152")
+
+
+class WeSpeakerResNet221(WeSpeakerResNet34):
+    ARCHITECTURE = ("pyannote.audio.models.embedding.wespeaker", "WeSpeakerResNet221")
+
+
+class WeSpeakerResNet293(WeSpeakerResNet34):
+    ARCHITECTURE = ("pyannote.audio.models.embedding.wespeaker", "WeSpeakerResNet293")
 
 
 # ---------------------------------------------------------------------------------------------

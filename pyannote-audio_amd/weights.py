@@ -231,7 +231,7 @@ class EmbeddingPack:
     State-dict layout: resnet.conv1/bn1, resnet.layer{1..4}.{i}.{conv1,bn1,conv2,bn2,shortcut.0,
     shortcut.1}, resnet.seg_1."""
 
-    def __init__(self, state_dict: dict, device: torch.device, num_blocks=(3, 4, 6, 3),
+    def __init__(self, state_dict: dict, device: torch.device, num_blocks=None,
                  num_mel: int = 80, sample_rate: int = 16000, winograd: Optional[bool] = None):
         if winograd is None:
             winograd = os.environ.get("PA_WINOGRAD", "1") != "0"
@@ -241,6 +241,16 @@ class EmbeddingPack:
         self._keep: list[torch.Tensor] = []
         w = ffi.EmbWeights()
         w.num_mel, w.num_layers = num_mel, 4
+        # architecture from the keys: Bottleneck blocks have a conv3 (resnet.py:148-212); block counts =
+        # highest block index per layer (ResNet34 3,4,6,3 / 152: 3,8,36,3 / 221: 6,16,48,3 / 293: 10,20,64,3)
+        self.bottleneck = "resnet.layer1.0.conv3.weight" in sd
+        if num_blocks is None:
+            num_blocks = [1 + max(int(k.split(".")[2]) for k in sd if k.startswith(f"resnet.layer{l + 1}."))
+                          for l in range(4)]
+        self.num_blocks = tuple(int(n) for n in num_blocks)
+        if sum(self.num_blocks) > ffi.PA_MAX_RES_BLOCKS:
+            raise NotImplementedError(f"{sum(self.num_blocks)} residual blocks > {ffi.PA_MAX_RES_BLOCKS}")
+        w.bottleneck = int(self.bottleneck)
         planes = [sd[f"resnet.layer{l + 1}.0.conv1.weight"].shape[0] for l in range(4)]
         if planes[0] != 32:
             raise NotImplementedError("stem kernel is built for m_channels = 32")
@@ -271,15 +281,31 @@ class EmbeddingPack:
         for l in range(4):
             for i in range(num_blocks[l]):
                 pre = f"resnet.layer{l + 1}.{i}"
-                for j, (cn, bn) in enumerate((("conv1", "bn1"), ("conv2", "bn2")), 1):
-                    sc, sh = _fold_bn(sd, f"{pre}.{bn}")
-                    cw = sd[f"{pre}.{cn}.weight"] * sc.view(-1, 1, 1, 1)  # (cout,cin,3,3)
-                    img = cw.permute(2, 3, 0, 1).reshape(9, cw.shape[0], cw.shape[1])
-                    getattr(w, f"blk_w{j}")[blk] = self._up(img).value
-                    getattr(w, f"blk_shift{j}")[blk] = self._up(sh).value
-                    stride = 2 if (j == 1 and i == 0 and l > 0) else 1
-                    if winograd and stride == 1:
-                        getattr(w, f"blk_u{j}")[blk] = self._up(winograd_pack(winograd_weights(cw))).value
+                first_stride = 2 if (i == 0 and l > 0) else 1
+                if self.bottleneck:
+                    # 1x1 -> 3x3 (stride) -> 1x1, BatchNorm folded into each (resnet.py:148-212)
+                    sc, sh = _fold_bn(sd, f"{pre}.bn1")
+                    w.blk_w1[blk] = self._up(sd[f"{pre}.conv1.weight"][:, :, 0, 0] * sc.view(-1, 1)).value
+                    w.blk_shift1[blk] = self._up(sh).value
+                    sc, sh = _fold_bn(sd, f"{pre}.bn2")
+                    cw = sd[f"{pre}.conv2.weight"] * sc.view(-1, 1, 1, 1)
+                    w.blk_w2[blk] = self._up(cw.permute(2, 3, 0, 1).reshape(9, cw.shape[0], cw.shape[1])).value
+                    w.blk_shift2[blk] = self._up(sh).value
+                    if winograd and first_stride == 1:
+                        w.blk_u2[blk] = self._up(winograd_pack(winograd_weights(cw))).value
+                    sc, sh = _fold_bn(sd, f"{pre}.bn3")
+                    w.blk_w3[blk] = self._up(sd[f"{pre}.conv3.weight"][:, :, 0, 0] * sc.view(-1, 1)).value
+                    w.blk_shift3[blk] = self._up(sh).value
+                else:
+                    for j, (cn, bn) in enumerate((("conv1", "bn1"), ("conv2", "bn2")), 1):
+                        sc, sh = _fold_bn(sd, f"{pre}.{bn}")
+                        cw = sd[f"{pre}.{cn}.weight"] * sc.view(-1, 1, 1, 1)  # (cout,cin,3,3)
+                        img = cw.permute(2, 3, 0, 1).reshape(9, cw.shape[0], cw.shape[1])
+                        getattr(w, f"blk_w{j}")[blk] = self._up(img).value
+                        getattr(w, f"blk_shift{j}")[blk] = self._up(sh).value
+                        stride = first_stride if j == 1 else 1
+                        if winograd and stride == 1:
+                            getattr(w, f"blk_u{j}")[blk] = self._up(winograd_pack(winograd_weights(cw))).value
                 if f"{pre}.shortcut.0.weight" in sd:
                     sc, sh = _fold_bn(sd, f"{pre}.shortcut.1")
                     cw = sd[f"{pre}.shortcut.0.weight"][:, :, 0, 0] * sc.view(-1, 1)

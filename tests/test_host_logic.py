@@ -185,3 +185,31 @@ def test_error_behaviour(synthetic_models, tmp_path):
     assert D.set_num_speakers() == (None, 1, np.inf)
     with pytest.raises(TypeError):
         Inference(m).to("cuda:0")
+
+
+def test_bottleneck_checkpoint_loader(tmp_path):
+    """WeSpeakerResNet152/221/293 checkpoints (Bottleneck blocks, wespeaker/resnet.py:148-212, 477-507):
+    the loader picks the class from the checkpoint's architecture name, reads depth / block type from
+    the state-dict keys, and the frame geometry follows the 1-3-1 kernels."""
+    from oracle.models import Bottleneck, WeSpeakerResNet34 as OracleNet
+    from pyannote_audio_amd.model import (Model, WeSpeakerResNet152, embedding_specifications,
+                                          save_checkpoint)
+    from pyannote_audio_amd.weights import EmbeddingPack
+    from conftest import WESPEAKER_HPARAMS
+    net = OracleNet(num_blocks=(1, 2, 1, 1), block=Bottleneck)
+    save_checkpoint(tmp_path / "pytorch_model.bin", net.state_dict(), WESPEAKER_HPARAMS,
+                    WeSpeakerResNet152.ARCHITECTURE, embedding_specifications())
+    m = Model.from_pretrained(str(tmp_path))
+    assert isinstance(m, WeSpeakerResNet152) and m._bottleneck and m._num_blocks == [1, 2, 1, 1]
+    assert m.dimension == 256
+    assert m.num_frames(160000) == 125 and m.num_frames(48000) == 38      # same strides as ResNet34
+    # with the reference's formula (utils/receptive_field.py: padded 3x3 convolutions do not widen the
+    # field) both block types see one 25 ms fbank window per output frame
+    basic = OracleNet(num_blocks=(1, 2, 1, 1))
+    from pyannote_audio_amd.model import WeSpeakerResNet34
+    mb = WeSpeakerResNet34(basic.state_dict(), WESPEAKER_HPARAMS, embedding_specifications())
+    assert m.receptive_field_size() == mb.receptive_field_size() == 400
+    assert m.receptive_field_center() == mb.receptive_field_center()
+    pack = EmbeddingPack(net.state_dict(), torch.device("cpu"))
+    assert pack.bottleneck and pack.num_blocks == (1, 2, 1, 1) and pack.struct.bottleneck == 1
+    assert EmbeddingPack(basic.state_dict(), torch.device("cpu")).struct.bottleneck == 0
