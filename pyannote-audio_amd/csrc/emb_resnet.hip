@@ -193,39 +193,49 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
       __syncthreads();
       if (c0 + CB < CIN) gload(cur, c0 + CB);
       else if (tn < total_tiles) gload(nxt, 0);
-      // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure)
+      // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure).
+      // Prefetching the fragments of tap+1 under the MFMAs of tap with a pinned schedule -- what the
+      // Winograd kernel needs -- was measured neutral here (79.4 vs 79.5 ms per audio-hour): two
+      // workgroups per CU already cover the LDS latency of this loop.
+      float4 af[1][MPW][2], bf[1][NT][2];
+      auto load_tap = [&](int tap, float4 (&a)[MPW][2], float4 (&bq)[NT][2]) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+          const int mt = wv * MPW + i;
+          const int yy = mt / TWT, xt = mt % TWT;
+          int off;
+          if (S == 1) off = ((yy + dy) * G::PW + 32 * xt + li + dx) * CLD;
+          else off = (((yy * 2 + dy) * 2 + (dx & 1)) * G::PWH + 32 * xt + li + (dx >> 1)) * CLD;
+          a[i][0] = *reinterpret_cast<const float4*>(patch + off + kh * 8);
+          a[i][1] = *reinterpret_cast<const float4*>(patch + off + kh * 8 + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int off = (tap * BN + 32 * j + li) * CLD + kh * 8;
+          bq[j][0] = *reinterpret_cast<const float4*>(wts + off);
+          bq[j][1] = *reinterpret_cast<const float4*>(wts + off + 4);
+        }
+      };
+      auto mfma_tap = [&](const float4 (&a)[MPW][2], const float4 (&bq)[NT][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < MPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              acc[i][j] = MFMA32(a[i][h].x, bq[j][h].x, acc[i][j]);
+              acc[i][j] = MFMA32(a[i][h].y, bq[j][h].y, acc[i][j]);
+              acc[i][j] = MFMA32(a[i][h].z, bq[j][h].z, acc[i][j]);
+              acc[i][j] = MFMA32(a[i][h].w, bq[j][h].w, acc[i][j]);
+            }
+      };
 #pragma unroll 1
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          float4 af[MPW][2], bf[NT][2];
-#pragma unroll
-          for (int i = 0; i < MPW; ++i) {
-            const int mt = wv * MPW + i;
-            const int yy = mt / TWT, xt = mt % TWT;
-            int off;
-            if (S == 1) off = ((yy + dy) * G::PW + 32 * xt + li + dx) * CLD;
-            else off = (((yy * 2 + dy) * 2 + (dx & 1)) * G::PWH + 32 * xt + li + (dx >> 1)) * CLD;
-            af[i][0] = *reinterpret_cast<const float4*>(patch + off + kh * 8);
-            af[i][1] = *reinterpret_cast<const float4*>(patch + off + kh * 8 + 4);
-          }
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int off = ((dy * 3 + dx) * BN + 32 * j + li) * CLD + kh * 8;
-            bf[j][0] = *reinterpret_cast<const float4*>(wts + off);
-            bf[j][1] = *reinterpret_cast<const float4*>(wts + off + 4);
-          }
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < MPW; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) {
-                acc[i][j] = MFMA32(af[i][h].x, bf[j][h].x, acc[i][j]);
-                acc[i][j] = MFMA32(af[i][h].y, bf[j][h].y, acc[i][j]);
-                acc[i][j] = MFMA32(af[i][h].z, bf[j][h].z, acc[i][j]);
-                acc[i][j] = MFMA32(af[i][h].w, bf[j][h].w, acc[i][j]);
-              }
+          load_tap(dy * 3 + dx, af[0], bf[0]);
+          mfma_tap(af[0], bf[0]);
         }
     }
     // ---- epilogue: lane holds channel n0 + 32j + li, pixels x = x0 + 32xt + (r&3) + 8(r>>2) + 4kh.
@@ -370,20 +380,16 @@ int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, co
   // algorithmic work: 2*9*cin*cout per output pixel; bytes: input + output (+ residual) + weights once
   pa::ProfScope prof("k_conv3x3", stream, 2.0 * 9 * cin * cout * (double)B * Ho * Wo_,
                      4.0 * ((double)B * H * W * cin + (double)B * Ho * Wo_ * cout * (R ? 2 : 1) + 9.0 * cin * cout));
-  static const int l1_wide = getenv("PA_CONV_L1_WIDE") ? atoi(getenv("PA_CONV_L1_WIDE")) : 0;  // tuning aid
   if (stride == 1) {
-    if (cout == 32 && l1_wide) pa::launch_conv<1, 8, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
-    else if (cout == 32) pa::launch_conv<1, 8, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    if (cout == 32) pa::launch_conv<1, 8, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else if (Ho >= 32) pa::launch_conv<1, 8, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else if (Ho >= 16) pa::launch_conv<1, 4, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
     else pa::launch_conv<1, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
   } else if (stride == 2) {
     PA_REQUIRE(cout % 64 == 0, "pa_conv3x3: stride 2 needs cout %% 64 == 0");
-    static const int s2bn32 = getenv("PA_CONV_S2_BN32") ? atoi(getenv("PA_CONV_S2_BN32")) : 1;  // 2 WG/CU: +4-7 %
-    if (s2bn32 && Ho >= 16) pa::launch_conv<2, 4, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
-    else if (s2bn32) pa::launch_conv<2, 2, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
-    else if (Ho >= 16) pa::launch_conv<2, 4, 1, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
-    else pa::launch_conv<2, 2, 2, 64>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    // 32-cout tiles: two workgroups per CU (+4-7 % over 64-cout tiles, measured in round 1)
+    if (Ho >= 16) pa::launch_conv<2, 4, 1, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
+    else pa::launch_conv<2, 2, 2, 32>(X, B, H, W, cin, Wg, shift, R, Y, cout, relu, st);
   } else {
     PA_REQUIRE(false, "pa_conv3x3: stride %d not supported", stride);
   }
