@@ -443,6 +443,8 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if getattr(pipeline, "batch_timeline", None):   # host-clock stage boundaries of the timed files
+            line["batch_timeline_s"] = [{k: round(v, 4) for k, v in f.items()} for f in pipeline.batch_timeline]
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             hour = None
             if "embeddings" in artifacts and "segmentation" in artifacts:

@@ -35,10 +35,6 @@ const char* pa_last_error(void);
  * a JSON object {"kernel": {"launches", "ms", "flops", "bytes"}} (algorithmic flops/bytes) into buf,
  * clears the records and returns the size needed. */
 void pa_prof_enable(int on);
-/* Leave `n` CUs free of the persistent convolution kernels (their grid is sized to the resident
- * workgroups) so that a single-workgroup kernel of another stream -- the dendrogram merge of the previous
- * file in SpeakerDiarization.apply_batch -- gets a CU without stretching them.  Default 0. */
-void pa_set_reserved_cus(int n);
 size_t pa_prof_report(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------------

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ R, float* __restrict__ Y,
                                                     int Ho, int Wo, int COUT, int relu, int tiles_w,
-                                                    int tiles_hw, int n_tiles, int total_tiles) {
+                                                    int tiles_hw, int n_tiles, int total_tiles,
+                                                    int* __restrict__ counters) {
   using G = ConvGeom<S, TH, TWT>;
   constexpr int MT = TH * TWT;   // 32-pixel M-tiles per workgroup
   constexpr int MPW = MT / 4;    // M-tiles per wave
@@ -171,11 +172,24 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
     }
   };
 
-  int t = blockIdx.x;
-  if (t >= total_tiles) return;
+  // tiles are CLAIMED at run time (common.h: TileQueue), one tile ahead: thread 0 claims tile k+1 when
+  // tile k starts and publishes it through LDS during tile k's first stage, in time for the prefetch of
+  // its first channel block in tile k's last stage
+  __shared__ int s_next;
+  const TileQueue tq{counters, (int)(blockIdx.x & 7), (total_tiles + 7) >> 3};
+  if (tid == 0) s_next = tq_resolve_upto(tq, tq_claim_own(tq), total_tiles);
+  __syncthreads();
+  int t = s_next;
+  if (t < 0) {
+    if (tid == 0) tq_done(tq, gridDim.x);
+    return;
+  }
   Tile cur = decode(t);
   gload(cur, 0);
-  for (; t < total_tiles; t += gridDim.x) {
+  for (;;) {
+    int ahead = 0;
+    if (tid == 0) ahead = tq_claim_own(tq);
+    int tn = -1;
     f32x16 acc[MPW][NT];
 #pragma unroll
     for (int i = 0; i < MPW; ++i)
@@ -183,16 +197,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int tn = t + gridDim.x;
     Tile nxt = cur;
-    if (tn < total_tiles) nxt = decode(tn);
 
     for (int c0 = 0; c0 < CIN; c0 += CB) {
       __syncthreads();  // every wave is done reading the previous stage from LDS
       lstore();
+      if (c0 == 0 && tid == 0) s_next = tq_resolve_upto(tq, ahead, total_tiles);
       __syncthreads();
+      if (c0 == 0) {     // CIN >= 2 channel blocks: the next tile is known before the last stage
+        tn = s_next;
+        if (tn >= 0) nxt = decode(tn);
+      }
       if (c0 + CB < CIN) gload(cur, c0 + CB);
-      else if (tn < total_tiles) gload(nxt, 0);
+      else if (tn >= 0) gload(nxt, 0);
       // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure).
       // Prefetching the fragments of tap+1 under the MFMAs of tap with a pinned schedule -- what the
       // Winograd kernel needs -- was measured neutral here (79.4 vs 79.5 ms per audio-hour): two
@@ -293,8 +310,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
         }
       }
     }
+    if (tn < 0) break;
     cur = nxt;
   }
+  if (tid == 0) tq_done(tq, gridDim.x);
 }
 
 // dense rows for the 1x1 stride-2 shortcut: A[((b*Ho+y)*Wo+x)][c] = X[b][2y][2x][c]
@@ -338,12 +357,18 @@ static int launch_conv_r(const float* X, int B, int H, int W, int CIN, const flo
     resident_of[dev] = cus * per_cu;
     per_cu_of[dev] = per_cu;
   }
-  const int resident = resident_of[dev] - reserved_cus() * per_cu_of[dev];
+  // every resident workgroup is launched; tiles are claimed at run time (common.h: TileQueue)
+  const int resident = resident_of[dev] & ~7;
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / BN;
   const long total = (long)tiles_hw * n_tiles * B;
   const int grid = (int)(total < resident ? total : resident);
+  int* counters = tile_counters();
+  if (counters == nullptr) {
+    set_error("pa_conv3x3: cannot allocate the tile counters");
+    return 2;
+  }
   hipLaunchKernelGGL((k_conv3x3<S, TH, TWT, BN, HAS_R>), dim3(grid), dim3(256), lds, st, X, H, W, CIN, Wg,
-                     shift, R, Y, Ho, Wo, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total);
+                     shift, R, Y, Ho, Wo, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, counters);
   return 0;
 }
 

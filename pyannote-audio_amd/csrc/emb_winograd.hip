@@ -12,8 +12,11 @@
 //     V never touches LDS -- and feeds it straight to v_mfma_f32_16x16x4_f32 as the A operand: for each
 //     of the 16 transform points xi, D[tile][cout] += V_xi[tile][cin] * U_xi[cin][cout];
 //   * the accumulators of the 16 points (16 x 2 cout groups x 4 VGPRs) stay in registers over the whole
-//     cin loop; the inverse transform A^T M A is lane-local because a lane holds all 16 points of its
-//     (tile, cout) entries; epilogue = + BN shift (+ residual) (+ ReLU), branch-free buffer stores;
+//     cin loop.  U is the MFMA's A operand and V its B operand, so a lane ends up with FOUR CONSECUTIVE
+//     output channels of one tile for all 16 points: the inverse transform A^T M A is lane-local float4
+//     arithmetic (packed f32 adds; subtractions as v_pk_fma_f32 with an opaque -1) and the epilogue =
+//     + BN shift (+ residual) (+ ReLU) moves 16 bytes per access (8 stores + 8 residual loads per lane
+//     instead of 32 + 32), branch-free;
 //   * staging is LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing through VGPRs, the
 //     hardware bounds check zero-fills the halo): the input patch, de-interleaved by column parity so
 //     that the stride-2 tile walk reads consecutive LDS rows, and the U slab.  Rows are 64 B (16
@@ -27,6 +30,14 @@
 //     accumulator registers, epilogue addresses are incremental, and two independent workgroups per CU
 //     interleave at instruction granularity (a strict two-phase ping-pong of an 8-wave workgroup was
 //     measured 6 % slower: tools/probes/emb_winograd_pingpong.hip.txt).
+//   * where a stage's time goes (s_memtime stamps of an instrumented build, tools/wino_stamps.py, cycles per
+//     wave and stage on the 20 x 250 x 128 layer): barrier 90 | DMA issue 3 100-4 700 | wait 450-600 |
+//     barrier 200-270 | transform 700-1 240 | 128 MFMAs 4 190 | epilogue 1 000 (amortised) = 11 100, against
+//     2 x 4 096 for the two waves of a SIMD.  The DMA phase is long because its 15 instructions only issue in
+//     the gaps of the OTHER workgroup's MFMA stream (same for the epilogue's and the transform's vector
+//     instructions); a wave's own DMA spread through its own MFMA run costs 5-25 cycles per instruction
+//     (tools/probes/interleave_probe.py) but needs both LDS images double-buffered = one workgroup per CU.
+//     Raising the wave priority outside the MFMA run (s_setprio) does not change the picture.
 // Numerics: fp32 throughout; the transforms only add/subtract and the 1/2 factors of G are applied in
 // float64 on the host; error ~3x the direct form's (tests: |err| <= 1e-4 max|ref| per conv, end to end).
 #include "common.h"
@@ -37,7 +48,29 @@
 #define WINO_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+#ifndef PA_WINO_STAMP
+#define PA_WINO_STAMP 0
+#endif
 namespace pa {
+
+#if PA_WINO_STAMP
+// development instrumentation (never in the product build): s_memtime stamps of the phases of the first
+// 64 stages of the first 16 workgroups, per wave; read back with pa_wino_read_stamps
+constexpr int STAMP_WG = 16, STAMP_IT = 64, STAMP_PH = 8;
+__device__ unsigned long long g_wino_stamps[STAMP_WG * 4 * STAMP_IT * STAMP_PH];
+#define WINO_STAMP(p) st_[p] = __builtin_amdgcn_s_memtime()
+#define WINO_STAMP_FLUSH()                                                                    \
+  do {                                                                                        \
+    if (blockIdx.x < STAMP_WG && st_iter < STAMP_IT && lane == 0) {                            \
+      _Pragma("unroll") for (int p_ = 0; p_ < STAMP_PH; ++p_)                                  \
+          g_wino_stamps[((blockIdx.x * 4 + slw) * STAMP_IT + st_iter) * STAMP_PH + p_] = st_[p_]; \
+    }                                                                                         \
+    ++st_iter;                                                                                \
+  } while (0)
+#else
+#define WINO_STAMP(p)
+#define WINO_STAMP_FLUSH()
+#endif
 
 constexpr int WCB = 16;   // input channels per stage (one 64-B LDS row)
 constexpr int W_BN = 32;  // output channels per workgroup
@@ -58,6 +91,17 @@ struct WinoGeom {
   static constexpr int USLAB = 16 * W_BN * WCB;     // floats
   static constexpr int LDS_FLOATS = PATCH + USLAB;
 };
+
+// Workgroup barrier WITHOUT the release/acquire fence of __syncthreads(): the fence drains vmcnt, i.e. it
+// would wait for the epilogue's global stores and for the patch that is being prefetched.  What has to
+// be ordered here is LDS only: a wave's ds_reads have returned before it gets here (their results were
+// consumed), and the LDS-DMA writes are awaited explicitly (s_waitcnt vmcnt) before the barrier that
+// publishes them.  The empty asm statements keep the compiler from moving memory operations across.
+__device__ __forceinline__ void wino_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 // physical 16-B slot of logical channel quad g in LDS row r
 __device__ __forceinline__ int wslot(int r, int g) { return (g + 2 * ((r >> 2) & 1)) & 3; }
@@ -136,31 +180,57 @@ __device__ __forceinline__ void wino_issue_u(const float* __restrict__ U, int CI
   }
 }
 
+// a - b on a float4 as two v_pk_fma_f32 (b * (-1) + a, exact).  The compiler scalarises a vector
+// subtraction into four v_sub_f32 (there is no packed subtract) and folds a literal -1 back into one, so the
+// -1 comes from an opaque scalar move; every vector instruction here is paid in matrix time.
+__device__ __forceinline__ float wino_minus_one() {
+  float m;
+  asm("s_mov_b32 %0, 0xbf800000" : "=s"(m));
+  return m;
+}
+__device__ __forceinline__ f32x4 vsub(const f32x4 a, const f32x4 b, const float m1) {
+  const f32x4 m = {m1, m1, m1, m1};
+  return __builtin_elementwise_fma(b, m, a);
+}
+
+// Patch reads of the input transform: tile (wr, 16 wc + t), patch element (i, j) lives in LDS row
+// R + K_ij with R = 4 wr PWH + 16 wc + t (per lane) and K_ij = (2i + (j & 1)) PWH + (j >> 1) (compile time).
+// The quad swizzle of a row only looks at bit 2 of the row number, i.e. at (R + K_ij mod 8): 8 per-lane
+// byte offsets (one per residue) computed once per kernel, everything else is a ds_read immediate.
+template <int TR, int TCG>
+__device__ __forceinline__ void wino_patch_bases(int (&pbase)[8], int t, int g, int wr, int wc) {
+  using G = WinoGeom<TR, TCG>;
+  const int R = 4 * wr * G::PWH + 16 * wc + t;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) pbase[c] = (R + c) * (WCB * 4) + 16 * wslot(R + c, g);
+}
+
 // input transform V = B^T d B of tile (wr, 16*wc + t) for channels 4g..4g+3, in registers
 template <int TR, int TCG>
-__device__ __forceinline__ void wino_transform(const float* patch, f32x4 (&v)[4][4], int t, int g, int wr,
-                                               int wc) {
+__device__ __forceinline__ void wino_transform(const float* patch, const int (&pbase)[8], f32x4 (&v)[4][4],
+                                               float m1) {
   using G = WinoGeom<TR, TCG>;
+  const char* base = reinterpret_cast<const char*>(patch);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x4 d[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = ((2 * wr + i) * 2 + (j & 1)) * G::PWH + 16 * wc + t + (j >> 1);
-      d[j] = *reinterpret_cast<const f32x4*>(patch + row * WCB + 4 * wslot(row, g));
+      const int K = (2 * i + (j & 1)) * G::PWH + (j >> 1);
+      d[j] = *reinterpret_cast<const f32x4*>(base + pbase[K & 7] + (K & ~7) * (WCB * 4));
     }
-    v[i][0] = d[0] - d[2];
+    v[i][0] = vsub(d[0], d[2], m1);
     v[i][1] = d[1] + d[2];
-    v[i][2] = d[2] - d[1];
-    v[i][3] = d[1] - d[3];
+    v[i][2] = vsub(d[2], d[1], m1);
+    v[i][3] = vsub(d[1], d[3], m1);
   }
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) {
     const f32x4 r0 = v[0][bb], r1 = v[1][bb], r2 = v[2][bb], r3 = v[3][bb];
-    v[0][bb] = r0 - r2;
+    v[0][bb] = vsub(r0, r2, m1);
     v[1][bb] = r1 + r2;
-    v[2][bb] = r2 - r1;
-    v[3][bb] = r1 - r3;
+    v[2][bb] = vsub(r2, r1, m1);
+    v[3][bb] = vsub(r1, r3, m1);
   }
 }
 
@@ -196,76 +266,68 @@ __device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4
     // after 40, so back-to-back MFMAs on ONE accumulator would stall 8 cycles each
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      acc[xi][0] = MFMA16(av[ks], bf[xi % (PF + 1)][0][ks], (FIRST && ks == 0) ? zero : acc[xi][0]);
-      acc[xi][1] = MFMA16(av[ks], bf[xi % (PF + 1)][1][ks], (FIRST && ks == 0) ? zero : acc[xi][1]);
+      // U as the A operand (rows = output channels), V as B (columns = tiles): D[cout 4g + r][tile t],
+      // i.e. a lane ends up with FOUR CONSECUTIVE output channels of ONE tile -> 16-byte epilogue accesses
+      acc[xi][0] = MFMA16(bf[xi % (PF + 1)][0][ks], av[ks], (FIRST && ks == 0) ? zero : acc[xi][0]);
+      acc[xi][1] = MFMA16(bf[xi % (PF + 1)][1][ks], av[ks], (FIRST && ks == 0) ? zero : acc[xi][1]);
     }
     WINO_SCHED_BARRIER();
   }
 }
 
-// inverse transform + epilogue.  acc[xi][cg][r]: cout n0 + 16cg + t, tile column 16wc + 4g + r of tile
-// row wr: outputs (y0 + 2wr + p, x0 + 2(16wc + 4g + r) + qq), p, qq in {0, 1}.
-// Addressing is incremental (one v_add per element from scalar steps); rows below the image are past
-// num_records by themselves, so only the x bound needs a compare (2 per tile column r, shared by both
-// cout groups).
+// inverse transform + epilogue.
+// acc[xi][cg] (f32x4): tile (row wr, column 16wc + t), output channels n0 + 16cg + 4g + {0..3}: the four
+// outputs (y0 + 2wr + p, x0 + 2(16wc + t) + qq) of the tile are 16-byte vectors of consecutive channels in
+// the NHWC map -> 8 buffer_store_dwordx4 (+ 8 residual buffer_load_dwordx4, all issued before the inverse
+// transform so that their latency hides under its arithmetic) per lane instead of 32 + 32 dword accesses,
+// and the inverse transform A^T M A runs on float4 (packed f32 adds).  Rows below the image are past
+// num_records by themselves; the column bound needs one compare per output column.
 template <bool HAS_R>
 __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
                                               int COUT, const float* __restrict__ shift,
                                               const float* __restrict__ R, float* __restrict__ Y,
-                                              int relu, int t, int g, int wr, int wc) {
+                                              int relu, int t, int g, int wr, int wc, float m1) {
   constexpr int OOB = (int)0x80000000;
   const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
       Y + (long)q.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(HAS_R ? R + (long)q.b * H * W * COUT : Y), 0, H * W * COUT * 4, 0x00020000);
-  constexpr int NG = 8;  // groups (r, cg) of 4 outputs: gi = 2r + cg
-  const int xl = q.x0 + 2 * (16 * wc + 4 * g);
-  const int nvx = q.valid ? W - xl : 0;  // element (r, qq) is inside the image iff 2r + qq < nvx
-  const int obase = (((q.y0 + 2 * wr) * W + xl) * COUT + q.n0 + t) * 4;
+  const int xl = q.x0 + 2 * (16 * wc + t);
+  const bool in0 = q.valid && xl < W, in1 = q.valid && xl + 1 < W;
+  const int obase = (((q.y0 + 2 * wr) * W + xl) * COUT + q.n0 + 4 * g) * 4;
   const int srow = W * COUT * 4, spix = COUT * 4;
-  const float sh0 = shift[q.n0 + t], sh1 = shift[q.n0 + 16 + t];
-  int off[2][4];
-  float rv[2][4];
-  auto goffs = [&](int gi, int* o) {
-    const int r = gi >> 1, cg = gi & 1;
-    const int o0 = obase + 2 * r * spix + 64 * cg;
-    const bool in0 = 2 * r < nvx, in1 = 2 * r + 1 < nvx;
-    o[0] = in0 ? o0 : OOB;
-    o[1] = in1 ? o0 + spix : OOB;
-    o[2] = in0 ? o0 + srow : OOB;
-    o[3] = in1 ? o0 + srow + spix : OOB;
-  };
-  auto gres = [&](const int* o, float* vv) {
+  int off[4];
+  off[0] = in0 ? obase : OOB;
+  off[1] = in1 ? obase + spix : OOB;
+  off[2] = in0 ? obase + srow : OOB;
+  off[3] = in1 ? obase + srow + spix : OOB;
+  f32x4 rv[2][4];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      vv[e] = HAS_R ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrd, o[e], 0, 0)) : 0.f;
-  };
-  goffs(0, off[0]);
-  gres(off[0], rv[0]);
+      rv[cg][e] = HAS_R ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off[e] + 64 * cg, 0, 0))
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float lo = relu ? 0.f : -__builtin_inff();
+  const f32x4 lo4 = {lo, lo, lo, lo};
 #pragma unroll
-  for (int gi = 0; gi < NG; ++gi) {
-    if (gi + 1 < NG) {
-      goffs(gi + 1, off[(gi + 1) & 1]);
-      gres(off[(gi + 1) & 1], rv[(gi + 1) & 1]);
-    }
-    const int r = gi >> 1, cg = gi & 1;
-    const float sh = cg ? sh1 : sh0;
-    float s[4], dd[4];
+  for (int cg = 0; cg < 2; ++cg) {
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + q.n0 + 16 * cg + 4 * g);
+    f32x4 s[4], dd[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      s[a] = acc[4 * a + 0][cg][r] + acc[4 * a + 1][cg][r] + acc[4 * a + 2][cg][r];
-      dd[a] = acc[4 * a + 1][cg][r] - acc[4 * a + 2][cg][r] - acc[4 * a + 3][cg][r];
+      s[a] = acc[4 * a + 0][cg] + acc[4 * a + 1][cg] + acc[4 * a + 2][cg];
+      dd[a] = vsub(vsub(acc[4 * a + 1][cg], acc[4 * a + 2][cg], m1), acc[4 * a + 3][cg], m1);
     }
-    float o4[4];
+    f32x4 o4[4];
     o4[0] = s[0] + s[1] + s[2];
     o4[1] = dd[0] + dd[1] + dd[2];
-    o4[2] = s[1] - s[2] - s[3];
-    o4[3] = dd[1] - dd[2] - dd[3];
+    o4[2] = vsub(vsub(s[1], s[2], m1), s[3], m1);
+    o4[3] = vsub(vsub(dd[1], dd[2], m1), dd[3], m1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float vv = o4[e] + sh + rv[gi & 1][e];
-      if (relu) vv = fmaxf(vv, 0.f);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, vv), ysrd, off[gi & 1][e], 0, 0);
+      const f32x4 vv = __builtin_elementwise_max(o4[e] + sh + rv[cg][e], lo4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), ysrd, off[e] + 64 * cg, 0, 0);
     }
   }
 }
@@ -297,7 +359,7 @@ template <int TR, int TCG, bool HAS_R>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
-    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb) {
+    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb, int* __restrict__ counters) {
   using G = WinoGeom<TR, TCG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -307,27 +369,63 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   float* patch = smem;
   float* uslab = smem + G::PATCH;
 
-  int q = blockIdx.x;
-  if (q >= total_tiles) return;
+  // tiles are CLAIMED, not statically strided (common.h: TileQueue): thread 0 claims the next tile while
+  // the current one is processed and publishes it through LDS at the tile boundary
+  int* s_next = reinterpret_cast<int*>(smem + G::LDS_FLOATS);
+  const TileQueue tq{counters, (int)(blockIdx.x & 7), total_tiles >> 3};
+  if (tid == 0) *s_next = tq_resolve(tq, tq_claim_own(tq));
+  __syncthreads();
+  int q = *s_next;
+  int ahead = 0;
   const int x0_last = (tiles_w - 1) * 32 * TCG;
   int prel[G::NPP];
   wino_patch_lanes<TR, TCG>(prel, W, CIN, lane, slw, x0_last);
   f32x4 acc[16][2];
-  for (; q < total_tiles; q += gridDim.x) {
-    const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
-    for (int c0 = 0; c0 < CIN; c0 += WCB) {
-      __syncthreads();  // every wave is done reading the previous stage
-      wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0, patch, prel, slw, x0_last);
-      wino_issue_u(U, CIN, COUT, cur.n0, c0, uslab, lane, slw);
-      __builtin_amdgcn_s_waitcnt(0x0F70);
+  int pbase[8];
+  wino_patch_bases<TR, TCG>(pbase, t, g, wr, wc);
+  const float m1 = wino_minus_one();
+#if PA_WINO_STAMP
+  unsigned long long st_[STAMP_PH] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int st_iter = 0;
+#endif
+  {
+    while (q >= 0) {
+      const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
+      if (tid == 0) ahead = tq_claim_own(tq);
+      for (int c0 = 0; c0 < CIN; c0 += WCB) {
+        WINO_STAMP(0);
+        wino_barrier();  // every wave is done reading the previous stage
+        WINO_STAMP(1);
+        wino_issue_patch<TR, TCG>(X, H, W, CIN, cur, c0, patch, prel, slw, x0_last);
+        wino_issue_u(U, CIN, COUT, cur.n0, c0, uslab, lane, slw);
+        WINO_STAMP(2);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        WINO_STAMP(3);
+        wino_barrier();
+        WINO_STAMP(4);
+        f32x4 v[4][4];
+        wino_transform<TR, TCG>(patch, pbase, v, m1);
+#if PA_WINO_STAMP
+        asm volatile("s_nop 0" ::"v"(v[3][3]), "v"(v[0][0]));   // the transform is complete here
+#endif
+        WINO_STAMP(5);
+        if (c0 == 0) wino_mfma<true>(uslab, v, acc, t, g);
+        else wino_mfma<false>(uslab, v, acc, t, g);
+        WINO_STAMP(6);
+        if (c0 + WCB < CIN) {
+          WINO_STAMP(7);
+          WINO_STAMP_FLUSH();
+        }
+      }
+      wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1);
+      WINO_STAMP(7);
+      WINO_STAMP_FLUSH();
+      if (tid == 0) *s_next = tq_resolve(tq, ahead);
       __syncthreads();
-      f32x4 v[4][4];
-      wino_transform<TR, TCG>(patch, v, t, g, wr, wc);
-      if (c0 == 0) wino_mfma<true>(uslab, v, acc, t, g);
-      else wino_mfma<false>(uslab, v, acc, t, g);
+      q = *s_next;
     }
-    wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc);
   }
+  if (tid == 0) tq_done(tq, gridDim.x);
 }
 
 template <int TR, int TCG, bool HAS_R>
@@ -335,7 +433,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
                          const float* R, float* Y, int COUT, int relu, hipStream_t st) {
   using G = WinoGeom<TR, TCG>;
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
-  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + 16;   // + the claimed-tile mailbox
   // per-device launch state (the attribute and the CU count belong to a device, not to the process)
   constexpr int MAXDEV = 16;
   static int resident_of[MAXDEV] = {0}, per_cu_of[MAXDEV] = {0};
@@ -356,10 +454,17 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
   const long num_pb = (long)tiles_hw * B;                    // (pixel tile, image) pairs
   const long total = ((num_pb + 7) / 8) * 8 * n_tiles;       // padded to whole XCD stripes
-  const int resident = resident_of[dev] - reserved_cus() * per_cu_of[dev];
+  // every resident workgroup is launched whatever else runs on the chip: tiles are claimed at run time, so
+  // a workgroup that is placed late (a foreign kernel holds its CU) costs nothing but its own absence
+  const int resident = resident_of[dev] & ~7;
   const int grid = (int)(total < resident ? total : resident);
+  int* counters = tile_counters();
+  if (counters == nullptr) {
+    set_error("pa_conv3x3_wino: cannot allocate the tile counters");
+    return 2;
+  }
   hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R>), dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift,
-                     R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, (int)num_pb);
+                     R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, (int)num_pb, counters);
   return 0;
 }
 
@@ -373,6 +478,20 @@ static int launch_wino(const float* X, int B, int H, int W, int CIN, const float
 }  // namespace pa
 
 extern "C" {
+
+#if PA_WINO_STAMP
+int pa_wino_read_stamps(unsigned long long* host, int zero) {
+  const size_t n = sizeof(unsigned long long) * pa::STAMP_WG * 4 * pa::STAMP_IT * pa::STAMP_PH;
+  (void)hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pa::g_wino_stamps), n) != hipSuccess) return 1;
+  if (zero) {
+    void* d = nullptr;
+    (void)hipGetSymbolAddress(&d, HIP_SYMBOL(pa::g_wino_stamps));
+    (void)hipMemset(d, 0, n);
+  }
+  return 0;
+}
+#endif
 
 // conv3x3, stride 1, pad 1, via Winograd F(2x2,3x3): Y = [relu](conv(X) + shift [+ R]).
 // U: G g G^T (BatchNorm scale folded) in the slab layout of weights.winograd_pack:

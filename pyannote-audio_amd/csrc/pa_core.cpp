@@ -21,11 +21,24 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// CUs the persistent (grid = resident workgroups) kernels leave free, so that a long single-workgroup
-// kernel on another stream -- the dendrogram merge of the previous file -- does not push two of their
-// statically partitioned workgroups into a second round (pa_set_reserved_cus).
-static int g_reserved_cus = 0;
-int reserved_cus() { return g_reserved_cus; }
+// Pool of self-resetting tile-counter blocks (common.h): 4096 blocks of 16 ints per device, handed out in
+// rotation -- on one stream a block is always free again when its turn comes (launches are ordered), and
+// across streams 4096 launches would have to be in flight at once for two to meet.
+int* tile_counters() {
+  constexpr int MAXDEV = 16, BLOCKS = 4096;
+  static std::mutex mu;
+  static int* pool[MAXDEV] = {nullptr};
+  static unsigned next[MAXDEV] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= MAXDEV) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (pool[dev] == nullptr) {
+    if (hipMalloc((void**)&pool[dev], sizeof(int) * 16 * BLOCKS) != hipSuccess) return nullptr;
+    (void)hipMemset(pool[dev], 0, sizeof(int) * 16 * BLOCKS);
+  }
+  return pool[dev] + 16 * (next[dev]++ % BLOCKS);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Profiler: when enabled, every kernel launcher brackets its launch with two hipEvents recorded on
@@ -71,7 +84,6 @@ ProfScope::~ProfScope() {
 
 extern "C" {
 
-void pa_set_reserved_cus(int n) { pa::g_reserved_cus = n < 0 ? 0 : n; }
 
 int pa_version(void) { return 101; }
 const char* pa_last_error(void) { return pa::g_err; }

@@ -95,8 +95,6 @@ def load():
     lib.pa_lstm_rec.argtypes = [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp]
     lib.pa_classifier.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp,
                                   C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp]
-    lib.pa_set_reserved_cus.argtypes = [C.c_int]
-    lib.pa_set_reserved_cus.restype = None
     lib.pa_prof_enable.argtypes = [C.c_int]
     lib.pa_prof_enable.restype = None
     lib.pa_prof_report.argtypes = [C.c_char_p, C.c_size_t]

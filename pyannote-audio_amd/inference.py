@@ -6,6 +6,7 @@ gathered by the kernels through (offset, stride) arithmetic, instead of `unfold`
 one D2H copy per batch (the reference's hot loop #1, inference.py:295-305)."""
 from __future__ import annotations
 
+import time
 import warnings
 from typing import Callable, Optional, Tuple
 
@@ -60,6 +61,7 @@ class Inference(BaseInference):
         # device-side copy of the last hard segmentation, for the embedding stage
         self.last_device_output: Optional[torch.Tensor] = None
         self.last_host_output: Optional[np.ndarray] = None   # its host image (identity-checked)
+        self.last_enqueued: float = 0.0
 
     def to(self, device: torch.device) -> "Inference":
         if not isinstance(device, torch.device):
@@ -94,6 +96,7 @@ class Inference(BaseInference):
         logp, ml = engine.forward_strided(sub, step_size, end - begin, window_size,
                                           want_logp=want_logp, want_multilabel=not want_logp)
         self.last_device_output = ml
+        self.last_enqueued = time.perf_counter()     # host clock when the launch group was queued
         outputs = (logp if want_logp else ml.to(torch.float32)).cpu().numpy()
         self.last_host_output = None if want_logp else outputs
         if hook is not None:

@@ -71,6 +71,7 @@ class _FrontEnd:
     embeddings: Optional[np.ndarray] = None        # host, float32, (C, S, D)
     dev_emb: Optional[torch.Tensor] = None
     marks: list = field(default_factory=list)
+    enqueued: dict = field(default_factory=dict)   # host clock when a stage's launches were all queued
 
     @property
     def silent(self) -> bool:
@@ -263,6 +264,7 @@ class SpeakerDiarization(Pipeline):
         segmentations = self.get_segmentations(file, hook=hook, waveform=waveform, chunk_range=chunk_range)
         dev_seg = self._segmentation.last_device_output
         marks.append(("segmentation", time.perf_counter()))
+        enqueued = {"segmentation": self._segmentation.last_enqueued}
 
         dev_emb = active = clean = None
         if shard.world_size > 1:
@@ -280,13 +282,14 @@ class SpeakerDiarization(Pipeline):
         marks.append(("speaker_counting", time.perf_counter()))
         hook("speaker_counting", count)
         front = _FrontEnd(file=file, chunks=chunks, segmentations=segmentations, dev_seg=dev_seg,
-                          count=count, marks=marks)
+                          count=count, marks=marks, enqueued=enqueued)
         if np.nanmax(count.data) == 0.0:
             return front                       # nobody speaks: no embeddings (:617-629)
 
         if dev_emb is None:
             dev_emb, active, clean, batches = self._embed(waveform, dev_seg, chunks, 0,
                                                           self.embedding_exclude_overlap, hook)
+            front.enqueued["embeddings"] = time.perf_counter()
             front.embeddings = dev_emb.cpu().numpy()
             if hook is not None:
                 hook("embeddings", front.embeddings, total=batches, completed=batches)
@@ -393,8 +396,7 @@ class SpeakerDiarization(Pipeline):
         in input order.
 
         Default: per-file results identical to `apply`, software-pipelined -- clustering and the back
-        end of file i run on a second stream while the front end of file i+1 runs on the first; one CU
-        is kept free of the persistent convolution kernels for the dendrogram merge.
+        end of file i run on a second stream while the front end of file i+1 runs on the first.
         `joint_clustering=True`: ONE clustering over the embeddings of all files (of all ranks when
         torch.distributed is initialised and `parallel.set_shard` was not used to split single files):
         speakers get the same label in every file (BASELINE.json configs[4])."""
@@ -406,7 +408,6 @@ class SpeakerDiarization(Pipeline):
             return
         num_speakers, min_speakers, max_speakers = bounds
         side = torch.cuda.Stream(device=device)
-        lib = ffi.load()
 
         def tail(front: _FrontEnd, file_hook: Callable):
             if front.silent:
@@ -417,20 +418,35 @@ class SpeakerDiarization(Pipeline):
                 side.synchronize()
             return out
 
-        lib.pa_set_reserved_cus(1)
-        try:
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                in_flight = None
-                for file in files:
-                    file_hook = self.setup_hook(file, hook=hook)
-                    front = self._front_end(file, file_hook)
-                    if in_flight is not None:
-                        yield in_flight[0], in_flight[1].result()
-                    in_flight = (file, pool.submit(tail, front, file_hook))
+        # The dendrogram merge of file i is ONE workgroup that owns a CU for ~0.2 s per audio-hour while the
+        # front end of file i+1 runs.  The persistent convolution kernels CLAIM their tiles at run time
+        # (csrc/common.h: TileQueue), so the workgroups that cannot be placed beside the merge merely find
+        # nothing left to do; with the earlier static tile partition they started a whole round late and every
+        # convolution launch under the merge took 1.6x as long (tools/probes/interference_probe.py).
+        t_batch = time.perf_counter()
+        self.batch_timeline = []               # per file: host-clock offsets (s) of the stage boundaries
+
+        def tail_timed(front: _FrontEnd, file_hook: Callable, line: dict):
+            line["tail_start"] = time.perf_counter() - t_batch
+            out = tail(front, file_hook)
+            line["tail_done"] = time.perf_counter() - t_batch
+            return out
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            in_flight = None
+            for file in files:
+                file_hook = self.setup_hook(file, hook=hook)
+                line = {"front_start": time.perf_counter() - t_batch}
+                front = self._front_end(file, file_hook)
+                line.update({name: stamp - t_batch for name, stamp in front.marks[1:]})
+                line.update({name + "_queued": stamp - t_batch for name, stamp in front.enqueued.items()})
+                self.batch_timeline.append(line)
                 if in_flight is not None:
                     yield in_flight[0], in_flight[1].result()
-        finally:
-            lib.pa_set_reserved_cus(0)
+                line["submit"] = time.perf_counter() - t_batch
+                in_flight = (file, pool.submit(tail_timed, front, file_hook, line))
+            if in_flight is not None:
+                yield in_flight[0], in_flight[1].result()
 
     def _apply_jointly(self, files: List[dict], bounds, hook, device: torch.device):
         """front end per file; records of all files of all ranks gathered on the device; ONE clustering

@@ -1,5 +1,5 @@
 """Per-shape timing of pa_conv3x3 on the ResNet34 layer shapes (development aid; HIP events through
-the library profiler).  usage: python tools/bench_conv.py [B] [reps]"""
+the library profiler).  usage: [WINO=1] [ONLY_S1=1] [PA_LIB=variant.so] python tools/bench_conv.py [B] [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +14,8 @@ shapes = [  # (H, W, cin, cout, stride, residual)
     (80, T, 32, 32, 1, True), (80, T, 32, 64, 2, False), (40, 499, 64, 64, 1, True),
     (40, 499, 64, 128, 2, False), (20, 250, 128, 128, 1, True), (20, 250, 128, 256, 2, False),
     (10, 125, 256, 256, 1, True)]
+if os.environ.get("ONLY_S1") == "1":   # the stride-1 (Winograd) layers, with and without the residual input
+    shapes = [(H, W, ci, co, s, r) for (H, W, ci, co, s, _) in shapes if s == 1 for r in (False, True)]
 for (H, W, ci, co, s, res) in shapes:
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     X = torch.randn(B, H, W, ci, device=dev)
@@ -31,7 +33,8 @@ for (H, W, ci, co, s, res) in shapes:
             return
         ffi.check(lib.pa_conv3x3(ffi.ptr(X), B, H, W, ci, ffi.ptr(Wg), ffi.ptr(sh), ffi.ptr(R), ffi.ptr(Y),
                                  co, s, 1, ffi.stream()), "conv")
-    run(); torch.cuda.synchronize()
+    for _ in range(int(os.environ.get('WARM', '10'))): run()
+    torch.cuda.synchronize()
     ffi.prof_enable(True)
     for _ in range(reps): run()
     torch.cuda.synchronize()
@@ -39,5 +42,5 @@ for (H, W, ci, co, s, res) in shapes:
     r = rep.get("k_conv3x3_wino") or rep["k_conv3x3"]
     ffi.prof_enable(False)
     ms = r["ms"] / r["launches"]
-    print(f"conv {H}x{W} {ci}->{co} s{s}: {ms:.3f} ms  {r['flops']/r['ms']/1e9:.1f} TFLOP/s "
+    print(f"conv {H}x{W} {ci}->{co} s{s} res={int(res)}: {ms:.3f} ms  {r['flops']/r['ms']/1e9:.1f} TFLOP/s "
           f"({r['flops']/r['ms']/1e9/157.3*100:.1f}% of f32 MFMA peak)", flush=True)

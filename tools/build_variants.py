@@ -1,0 +1,39 @@
+"""Build A/B variants of one kernel file next to the product library (development aid): the variant's
+object replaces the product object at link time.  usage: python tools/build_variants.py
+Variants land in pyannote-audio_amd/build/variants/libpa_<tag>.so; select one with PA_LIB=<path>."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pyannote_audio_amd import _build
+
+VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or None for the work tree)
+    "head": ("emb_winograd.hip", "", "HEAD"),
+    "stamp": ("emb_winograd.hip", "-DPA_WINO_STAMP=1", None),
+}
+
+
+def main():
+    _build.build_library()
+    out = _build.PKG_DIR / "build" / "variants"
+    out.mkdir(parents=True, exist_ok=True)
+    objs = {p.name: p for p in (_build.PKG_DIR / "build").glob("*.o")}
+    for tag, (src, flags, rev) in VARIANTS.items():
+        path = _build.CSRC / src
+        if rev:
+            text = subprocess.check_output(["git", "show", f"{rev}:pyannote-audio_amd/csrc/{src}"], cwd=ROOT)
+            path = _build.CSRC / f"_variant_{tag}_{src}"
+            path.write_bytes(text)
+        obj = out / f"{tag}_{src}.o"
+        cmd = ["hipcc", f"--offload-arch={_build.ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", *flags.split(),
+               "-I", str(_build.PKG_DIR.parent / "include"), "-c", str(path), "-o", str(obj)]
+        subprocess.check_call(cmd)
+        if rev:
+            path.unlink()
+        link = [str(o) for name, o in objs.items() if name != src + ".o"] + [str(obj)]
+        lib = out / f"libpa_{tag}.so"
+        subprocess.check_call(["hipcc", f"--offload-arch={_build.ARCH}", "-shared", "-fPIC", "-o", str(lib)] + link)
+        print("built", lib)
+
+
+if __name__ == "__main__":
+    main()
