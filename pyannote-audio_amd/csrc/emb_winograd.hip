@@ -37,7 +37,12 @@
 //     the gaps of the OTHER workgroup's MFMA stream (same for the epilogue's and the transform's vector
 //     instructions); a wave's own DMA spread through its own MFMA run costs 5-25 cycles per instruction
 //     (tools/probes/interleave_probe.py) but needs both LDS images double-buffered = one workgroup per CU.
-//     Raising the wave priority outside the MFMA run (s_setprio) does not change the picture.
+//     Raising the wave priority outside the MFMA run (s_setprio) does not change the picture.  That
+//     one-workgroup-per-CU software-pipelined form was built (tools/probes/emb_winograd_sp.hip.txt: next
+//     stage's DMA and the residual loads issued from inside the MFMA run, one barrier per stage, results
+//     identical) and measured 10-17 % SLOWER (6 350 instead of 5 430 cycles per stage and wave on the
+//     128-channel layer): with nothing else on the SIMD its transform, descriptor arithmetic, barrier and
+//     epilogue are all exposed.  Two workgroups per CU stay.
 // Numerics: fp32 throughout; the transforms only add/subtract and the 1/2 factors of G are applied in
 // float64 on the host; error ~3x the direct form's (tests: |err| <= 1e-4 max|ref| per conv, end to end).
 #include "common.h"
@@ -237,9 +242,15 @@ __device__ __forceinline__ void wino_transform(const float* patch, const int (&p
 // 16 transform points x 2 cout groups x 4 k-steps; B fragments one point ahead of their MFMAs (a second
 // point of look-ahead does not fit the 256-VGPR budget, and what the reads cost is issue time, not latency).
 // FIRST: the first stage of a tile starts the accumulators from the inline constant 0 (no v_mov run).
-template <bool FIRST>
+struct WinoNoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `hook(xi)` runs after the MFMAs of point xi: the software-pipelined kernel issues the NEXT stage's DMA
+// pieces (and the residual loads of the epilogue) from there -- a wave's own memory instructions cost it
+// 5-25 cycles each inside its MFMA run (tools/probes/interleave_probe.py).
+template <bool FIRST, typename Hook = WinoNoHook>
 __device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4][4], f32x4 (&acc)[16][2],
-                                          int t, int g) {
+                                          int t, int g, const Hook& hook = Hook()) {
   constexpr int PF = 1;
   f32x4 bf[PF + 1][2];
   // row = 32 xi + 16 cg + t: its swizzle bit ((row >> 2) & 1) = (t >> 2) & 1 does not depend on xi / cg,
@@ -272,6 +283,8 @@ __device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4
       acc[xi][1] = MFMA16(bf[xi % (PF + 1)][1][ks], av[ks], (FIRST && ks == 0) ? zero : acc[xi][1]);
     }
     WINO_SCHED_BARRIER();
+    hook(xi);
+    WINO_SCHED_BARRIER();
   }
 }
 
@@ -282,32 +295,48 @@ __device__ __forceinline__ void wino_mfma(const float* uslab, const f32x4 (&v)[4
 // transform so that their latency hides under its arithmetic) per lane instead of 32 + 32 dword accesses,
 // and the inverse transform A^T M A runs on float4 (packed f32 adds).  Rows below the image are past
 // num_records by themselves; the column bound needs one compare per output column.
-template <bool HAS_R>
-__device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
-                                              int COUT, const float* __restrict__ shift,
-                                              const float* __restrict__ R, float* __restrict__ Y,
-                                              int relu, int t, int g, int wr, int wc, float m1) {
+// byte offsets of the tile's four output pixels for this lane (channels n0 + 4g .., cg adds 64 bytes)
+__device__ __forceinline__ void wino_out_offsets(int (&off)[4], const WinoTile& q, int W, int COUT, int t, int g,
+                                                 int wr, int wc) {
   constexpr int OOB = (int)0x80000000;
-  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
-      Y + (long)q.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(HAS_R ? R + (long)q.b * H * W * COUT : Y), 0, H * W * COUT * 4, 0x00020000);
   const int xl = q.x0 + 2 * (16 * wc + t);
   const bool in0 = q.valid && xl < W, in1 = q.valid && xl + 1 < W;
   const int obase = (((q.y0 + 2 * wr) * W + xl) * COUT + q.n0 + 4 * g) * 4;
   const int srow = W * COUT * 4, spix = COUT * 4;
-  int off[4];
   off[0] = in0 ? obase : OOB;
   off[1] = in1 ? obase + spix : OOB;
   off[2] = in0 ? obase + srow : OOB;
   off[3] = in1 ? obase + srow + spix : OOB;
+}
+
+// PRE: the residual values were loaded by the caller (inside the last MFMA run) into `rv`
+template <bool HAS_R, bool PRE = false>
+__device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
+                                              int COUT, const float* __restrict__ shift,
+                                              const float* __restrict__ R, float* __restrict__ Y,
+                                              int relu, int t, int g, int wr, int wc, float m1,
+                                              const int* off_pre = nullptr, f32x4 (*rv_pre)[4] = nullptr) {
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
+      Y + (long)q.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(HAS_R ? R + (long)q.b * H * W * COUT : Y), 0, H * W * COUT * 4, 0x00020000);
+  int off[4];
+  if (PRE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) off[e] = off_pre[e];
+  } else {
+    wino_out_offsets(off, q, W, COUT, t, g, wr, wc);
+  }
   f32x4 rv[2][4];
 #pragma unroll
   for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      rv[cg][e] = HAS_R ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off[e] + 64 * cg, 0, 0))
-                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) {
+      if (PRE && HAS_R) rv[cg][e] = rv_pre[cg][e];
+      else
+        rv[cg][e] = HAS_R ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off[e] + 64 * cg, 0, 0))
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   const float lo = relu ? 0.f : -__builtin_inff();
   const f32x4 lo4 = {lo, lo, lo, lo};
 #pragma unroll
@@ -434,6 +463,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   using G = WinoGeom<TR, TCG>;
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
   const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + 16;   // + the claimed-tile mailbox
+  auto kernel = k_conv3x3_wino<TR, TCG, HAS_R>;
   // per-device launch state (the attribute and the CU count belong to a device, not to the process)
   constexpr int MAXDEV = 16;
   static int resident_of[MAXDEV] = {0}, per_cu_of[MAXDEV] = {0};
@@ -441,11 +471,10 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= MAXDEV) dev = 0;
   if (!resident_of[dev]) {
-    (void)hipFuncSetAttribute((const void*)k_conv3x3_wino<TR, TCG, HAS_R>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int cus = 256, per_cu = 2;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3_wino<TR, TCG, HAS_R>, 256, lds) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) !=
             hipSuccess || per_cu < 1)
       per_cu = 2;
     resident_of[dev] = cus * per_cu;
@@ -463,8 +492,8 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
     set_error("pa_conv3x3_wino: cannot allocate the tile counters");
     return 2;
   }
-  hipLaunchKernelGGL((k_conv3x3_wino<TR, TCG, HAS_R>), dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift,
-                     R, Y, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, (int)num_pb, counters);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, tiles_w,
+                     tiles_hw, n_tiles, (int)total, (int)num_pb, counters);
   return 0;
 }
 

@@ -7,7 +7,6 @@ sys.path.insert(0, ROOT)
 from pyannote_audio_amd import _build
 
 VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or None for the work tree)
-    "head": ("emb_winograd.hip", "", "HEAD"),
     "stamp": ("emb_winograd.hip", "-DPA_WINO_STAMP=1", None),
 }
 
