@@ -8,6 +8,7 @@ io.py:258-262) with the filter bank evaluated on the host in the waveform's dtyp
 from __future__ import annotations
 
 import math
+from io import IOBase
 from pathlib import Path
 from typing import Mapping, Optional, Tuple, Union
 
@@ -16,7 +17,7 @@ import torch
 
 from .core import Segment
 
-AudioFile = Union[str, Path, Mapping]
+AudioFile = Union[str, Path, IOBase, Mapping]
 
 
 def sinc_resample_bank(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
@@ -71,8 +72,11 @@ class Audio:
             pass
         elif isinstance(file, (str, Path)):
             file = {"audio": str(file), "uri": Path(file).stem}
+        elif isinstance(file, IOBase):       # open("audio.wav", "rb"): io.py:180-181
+            return {"audio": file, "uri": "stream"}
         else:
-            raise ValueError("AudioFile must be a path or a mapping with 'waveform' or 'audio' keys")
+            raise ValueError("AudioFile must be a path, a binary file object or a mapping with "
+                             "'waveform' or 'audio' keys")
         if "waveform" in file:
             waveform = file["waveform"]
             if len(waveform.shape) != 2 or waveform.shape[0] > waveform.shape[1]:
@@ -82,6 +86,8 @@ class Audio:
             file = dict(file)
             file.setdefault("uri", "waveform")
         elif "audio" in file:
+            if isinstance(file["audio"], IOBase):
+                return file
             if not Path(file["audio"]).is_file():
                 raise ValueError(f"File {file['audio']} does not exist")
             file = dict(file)
@@ -90,8 +96,11 @@ class Audio:
             raise ValueError("Neither 'waveform' nor 'audio' is available for this file.")
         return file
 
-    def downmix_and_resample(self, waveform: torch.Tensor, sample_rate: int
-                             ) -> Tuple[torch.Tensor, int]:
+    def downmix_and_resample(self, waveform: torch.Tensor, sample_rate: int,
+                             channel: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+        """io.py:223-265: channel selection, then down-mix, then resampling (on the GPU)."""
+        if channel is not None:
+            waveform = waveform[channel: channel + 1]
         num_channels = waveform.shape[0]
         if num_channels > 1:
             if self.mono == "random":
@@ -124,7 +133,11 @@ class Audio:
     @staticmethod
     def _read(path) -> Tuple[torch.Tensor, int]:
         from scipy.io import wavfile
-        sr, data = wavfile.read(str(path))
+        if isinstance(path, IOBase):
+            sr, data = wavfile.read(path)
+            path.seek(0)                     # rewind, as the reference does after decoding (io.py:348-349)
+        else:
+            sr, data = wavfile.read(str(path))
         if data.dtype == np.int16:
             x = data.astype(np.float32) / 32768.0
         elif data.dtype == np.int32:
@@ -146,33 +159,62 @@ class Audio:
             waveform, sample_rate = file["waveform"], file["sample_rate"]
         else:
             waveform, sample_rate = self._read(file["audio"])
-        channel = file.get("channel", None)
-        if channel is not None:
-            waveform = waveform[channel: channel + 1]
-        return self.downmix_and_resample(waveform, sample_rate)
+        return self.downmix_and_resample(waveform, sample_rate, channel=file.get("channel", None))
 
     def crop(self, file: AudioFile, segment: Segment, mode: str = "raise"
              ) -> Tuple[torch.Tensor, int]:
-        """io.py:353-484 (in-memory): fixed-size excerpt, zero padded when mode == 'pad'."""
-        waveform, sample_rate = self(file)
-        frames = waveform.shape[1]
-        start_frame = math.floor(segment.start * sample_rate)
-        num_frames = math.floor(segment.duration * sample_rate)
-        end_frame = start_frame + num_frames
-        if mode == "raise":
-            if num_frames > frames:
-                raise ValueError("requested fixed duration is longer than file duration")
-            if end_frame > frames + math.ceil(0.001 * sample_rate):
-                raise ValueError("requested chunk lies outside of file bounds")
-            end_frame = min(end_frame, frames)
-            start_frame = end_frame - num_frames
-            pad_start = pad_end = 0
-        else:
-            pad_start = -min(0, start_frame)
-            pad_end = max(end_frame, frames) - frames
-            start_frame = max(0, start_frame)
-            end_frame = min(end_frame, frames)
-        data = waveform[:, start_frame:end_frame]
-        if pad_start or pad_end:
-            data = torch.nn.functional.pad(data, (pad_start, pad_end))
-        return data, sample_rate
+        """io.py:353-484: the excerpt is cut at the FILE's rate and only then down-mixed / resampled.
+        `mode`: "raise" (out-of-bounds segments are an error) or "pad" (zero padding).
+
+        In-memory waveforms (:384-413): samples [round(start sr), round(end sr)); in "raise" mode an end
+        AT or beyond the last sample is an error (the reference compares with >=).  Files (:415-484): the
+        reference asks torchcodec for the samples played in [start, end) and repairs a +-1 sample difference
+        to round(duration sr); this build decodes PCM WAV completely (scipy) and applies the same
+        arithmetic, with torchcodec's range rounded to the nearest sample at both ends."""
+        file = self.validate_file(file)
+        channel = file.get("channel", None)
+        start, end = float(segment.start), float(segment.end)
+        if "waveform" in file:
+            waveform, sample_rate = file["waveform"], file["sample_rate"]
+            total = waveform.shape[1]
+            first, last = self.get_num_samples(start, sample_rate), self.get_num_samples(end, sample_rate)
+            if mode == "raise":
+                if first < 0:
+                    raise ValueError(f"requested chunk with negative start time (t={start:.3f}s)")
+                if last >= total:
+                    raise ValueError(f"requested chunk with end time (t={end:.3f}s) greater than "
+                                     f"{file.get('uri', 'in-memory')} file duration ({total / sample_rate:.3f}s).")
+            lead, trail = max(0, -first), max(last, total) - total
+            data = waveform[:, max(first, 0):min(last, total)]
+            if lead or trail:
+                data = torch.nn.functional.pad(data, (lead, trail))
+            return self.downmix_and_resample(data, sample_rate, channel=channel)
+
+        waveform, sample_rate = self._read(file["audio"])
+        total = waveform.shape[1]
+        duration = total / sample_rate
+        lead = max(0, self.get_num_samples(-start, sample_rate))
+        if start < 0:
+            if mode == "raise":
+                raise ValueError(f"requested chunk with negative start time (t={start:.3f}s)")
+            start = 0.0
+        trail = max(self.get_num_samples(end, sample_rate), total) - total
+        if end > duration:
+            if mode == "raise":
+                raise ValueError(f"requested chunk with end time (t={end:.3f}s) greater than "
+                                 f"{file.get('uri', 'in-memory')} file duration ({duration:.3f}s).")
+            end = duration
+        data = waveform[:, min(self.get_num_samples(start, sample_rate), total):
+                        min(self.get_num_samples(end, sample_rate), total)]
+        expected = self.get_num_samples(segment.duration, sample_rate)
+        difference = lead + data.shape[1] + trail - expected
+        if abs(difference) > 1:
+            raise ValueError(f"requested chunk {segment} from {file.get('uri', 'in-memory')} file resulted in "
+                             f"{data.shape[1]} samples instead of the expected {expected} samples.")
+        if difference == 1:
+            data = data[:, :-1]
+        elif difference == -1:
+            trail += 1
+        if lead or trail:
+            data = torch.nn.functional.pad(data, (lead, trail))
+        return self.downmix_and_resample(data, sample_rate, channel=channel)

@@ -1,0 +1,130 @@
+"""The audio front door against the behaviours the reference's own
+tests/io_test.py checks: channel selection, in-memory waveforms, fixed-size crops, paths and binary
+file objects (rewound after reading, core/io.py:348-349).  The reference decodes with torchcodec; here
+the fixture is a PCM WAV written by scipy (the decoder this build has).  Resampling runs on the GPU only
+(tests/test_resample_gpu.py): without one it must fail loudly, never fall back to a CPU resampler."""
+import io
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from pyannote_audio_amd.audio import Audio
+from pyannote_audio_amd.core import Segment
+
+
+@pytest.fixture
+def wav_file(tmp_path):
+    sr = 16000
+    rng = np.random.default_rng(5)
+    data = (rng.uniform(-0.5, 0.5, size=(2 * sr, 2)) * 32767).astype(np.int16)   # 2 s, stereo
+    path = tmp_path / "dev00.wav"
+    wavfile.write(path, sr, data)
+    return path, sr, data
+
+
+def test_basic_load_with_defaults(wav_file):                      # io_test.py:21-25
+    path, sr, data = wav_file
+    wav, rate = Audio(mono="downmix")(path)
+    assert isinstance(wav, torch.Tensor) and rate == sr and wav.shape == (1, data.shape[0])
+    expected = (data.astype(np.float32) / 32768.0).mean(axis=1)
+    assert torch.allclose(wav[0], torch.from_numpy(expected), atol=1e-7)
+
+
+def test_correct_audio_channel():                                  # io_test.py:28-35
+    waveform = torch.rand(2, 16000 * 2)
+    wav, sr = Audio(mono="downmix")({"waveform": waveform, "sample_rate": 16000, "channel": 1})
+    assert torch.equal(wav, waveform[1:2]) and sr == 16000
+
+
+def test_can_load_with_waveform():                                 # io_test.py:38-45
+    waveform = torch.rand(2, 16000 * 2)
+    wav, sr = Audio(mono="downmix")({"waveform": waveform, "sample_rate": 16000})
+    assert isinstance(wav, torch.Tensor) and sr == 16000 and wav.shape == (1, 32000)
+    assert torch.allclose(wav, waveform.mean(dim=0, keepdim=True))
+
+
+def test_can_crop(wav_file):                                       # io_test.py:48-54
+    path, _, _ = wav_file
+    wav, sr = Audio(mono="downmix").crop(path, Segment(0.2, 0.7))
+    assert wav.shape[1] / sr == 0.5
+
+
+def test_can_crop_waveform():                                      # io_test.py:57-65
+    waveform = torch.rand(1, 16000 * 2)
+    wav, sr = Audio(mono="downmix").crop({"waveform": waveform, "sample_rate": 16000}, Segment(0.2, 0.7))
+    assert isinstance(wav, torch.Tensor) and sr == 16000
+    assert torch.equal(wav, waveform[:, 3200:11200])
+
+
+def test_can_load_from_file_like(wav_file):                        # io_test.py:69-77
+    path, sr, data = wav_file
+    loader = Audio(mono="downmix")
+    with open(path, "rb") as f:
+        wav, rate = loader(f)
+        assert f.tell() == 0                                       # rewound for the next reader
+        again, _ = loader({"audio": f, "uri": "stream"})
+    assert isinstance(wav, torch.Tensor) and rate == sr and torch.equal(wav, again)
+    assert torch.equal(wav, loader(path)[0])
+
+
+def test_can_crop_from_file_like(wav_file):                        # io_test.py:80-90
+    path, sr, _ = wav_file
+    loader = Audio(mono="downmix")
+    with open(path, "rb") as f:
+        wav, rate = loader.crop(f, Segment(0.2, 0.7))
+    assert isinstance(wav, torch.Tensor) and rate == sr and wav.shape[1] == 0.5 * 16000
+    in_memory = io.BytesIO(open(path, "rb").read())
+    assert torch.equal(loader.crop(in_memory, Segment(0.2, 0.7))[0], wav)
+
+
+def test_validate_file_contract(tmp_path):                         # core/io.py:153-216
+    assert Audio.validate_file(io.BytesIO(b""))["uri"] == "stream"
+    with pytest.raises(ValueError):
+        Audio.validate_file({"waveform": torch.zeros(16000, 1), "sample_rate": 16000})   # (time, channel)
+    with pytest.raises(ValueError):
+        Audio.validate_file({"waveform": torch.zeros(1, 16000)})                          # no sample rate
+    with pytest.raises(ValueError):
+        Audio.validate_file(tmp_path / "missing.wav")
+    with pytest.raises(ValueError):
+        Audio.validate_file(3.14)
+
+
+def test_resampling_never_falls_back_to_the_cpu(wav_file):         # io_test.py:10-18 needs a GPU here
+    path, sr, _ = wav_file
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU by tests/test_resample_gpu.py")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Audio(sample_rate=sr // 2, mono="downmix")(path)
+
+
+def test_crop_bounds_follow_the_reference():                       # core/io.py:384-413 (in-memory), :433-455 (files)
+    sr = 16000
+    waveform = torch.arange(2 * sr, dtype=torch.float32)[None]
+    loader = Audio(mono="downmix")
+    file = {"waveform": waveform, "sample_rate": sr}
+    with pytest.raises(ValueError, match="negative start"):
+        loader.crop(file, Segment(-0.5, 0.5))
+    with pytest.raises(ValueError, match="greater than"):
+        loader.crop(file, Segment(1.5, 2.0))                       # an end AT the last sample raises (>=)
+    wav, _ = loader.crop(file, Segment(1.5, 2.0 - 1.0 / sr))
+    assert wav.shape[1] == 7999 and wav[0, 0] == 24000
+    wav, _ = loader.crop(file, Segment(-0.5, 0.5), mode="pad")
+    assert wav.shape[1] == sr and torch.all(wav[0, :8000] == 0) and wav[0, 8000] == 0 and wav[0, 8001] == 1
+    wav, _ = loader.crop(file, Segment(1.5, 2.5), mode="pad")
+    assert wav.shape[1] == sr and wav[0, 0] == 24000 and torch.all(wav[0, 8000:] == 0)
+
+
+def test_file_crop_bounds(wav_file):
+    path, sr, data = wav_file
+    loader = Audio(mono="downmix")
+    mono = torch.from_numpy((data.astype(np.float32) / 32768.0).mean(axis=1))
+    wav, _ = loader.crop(path, Segment(1.5, 2.0))                  # files: the end of the file is a valid end
+    assert wav.shape[1] == 8000 and torch.allclose(wav[0], mono[24000:], atol=1e-7)
+    with pytest.raises(ValueError, match="greater than"):
+        loader.crop(path, Segment(1.5, 2.5))
+    wav, _ = loader.crop(path, Segment(1.5, 2.5), mode="pad")
+    assert wav.shape[1] == sr and torch.all(wav[0, 8000:] == 0)
+    wav, _ = loader.crop({"audio": str(path), "channel": 1}, Segment(0.0, 0.25))
+    assert torch.allclose(wav[0], torch.from_numpy(data[:4000, 1].astype(np.float32) / 32768.0), atol=1e-7)
