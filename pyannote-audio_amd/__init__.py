@@ -16,3 +16,4 @@ from .plda import PLDA  # noqa: E402,F401
 from .speaker_verification import PretrainedSpeakerEmbedding  # noqa: E402,F401
 from .speaker_diarization import SpeakerDiarization, DiarizeOutput  # noqa: E402,F401
 from .voice_activity_detection import VoiceActivityDetection  # noqa: E402,F401
+from .hook import ArtifactHook, Hooks, ProgressHook, TimingHook  # noqa: E402,F401
