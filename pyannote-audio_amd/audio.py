@@ -65,6 +65,14 @@ class Audio:
         self.mono = mono
         self.device = device      # where resampling runs (set by SpeakerDiarization.to)
 
+    PRECISION = 0.001
+
+    @staticmethod
+    def power_normalize(waveform: torch.Tensor) -> torch.Tensor:
+        """unit RMS along time (io.py:134-151)"""
+        rms = waveform.square().mean(dim=-1, keepdim=True).sqrt()
+        return waveform / (rms + 1e-8)
+
     @staticmethod
     def validate_file(file: AudioFile) -> Mapping:
         """io.py:153-216"""

@@ -72,6 +72,48 @@ class Inference(BaseInference):
         return self
 
     # ---------------------------------------------------------------------------------------
+    def _forward(self, wav: torch.Tensor, stride: int, count: int, window: int, want_logp: bool,
+                 want_multilabel: bool):
+        """strided chunks of a flat device waveform through the segmentation engine; running out of
+        device memory is reported the way core/inference.py:199-208 reports it (MemoryError + advice)"""
+        try:
+            return self.model.engine.forward_strided(wav, stride, count, window, want_logp=want_logp,
+                                                     want_multilabel=want_multilabel)
+        except (MemoryError, torch.OutOfMemoryError):
+            raise MemoryError(f"batch_size ({self.batch_size: d}) is probably too large. "
+                              f"Try with a smaller value until memory error disappears.") from None
+
+    def infer(self, chunks: torch.Tensor) -> np.ndarray:
+        """(batch, 1, samples) chunks -> (batch, frames, classes) numpy, converted from powerset to hard
+        multilabel unless `skip_conversion` (core/inference.py:182-215)."""
+        if chunks.dim() != 3 or chunks.shape[1] != 1:
+            raise ValueError("`chunks` must be a (batch_size, 1, num_samples) tensor (mono models)")
+        batch, _, num_samples = chunks.shape
+        flat = chunks.to(self.model.device, torch.float32).contiguous().view(-1)
+        convert = bool(self.model.specifications.powerset) and not self.skip_conversion
+        logp, ml = self._forward(flat, num_samples, batch, num_samples, want_logp=not convert,
+                                 want_multilabel=convert)
+        return (ml.to(torch.float32) if convert else logp).cpu().numpy()
+
+    def crop(self, file: AudioFile, chunk, hook: Optional[Callable] = None):
+        """Inference on one excerpt, or on the smallest excerpt containing a list of them (sliding window),
+        or on their concatenation (whole window) -- core/inference.py:420-496.  Sliding-window output
+        frames start at the excerpt's start time."""
+        audio = Audio(self.model.audio.sample_rate, mono="downmix", device=self.device)
+        if self.window == "sliding":
+            if not isinstance(chunk, Segment):
+                chunk = Segment(min(c.start for c in chunk), max(c.end for c in chunk))
+            waveform, sample_rate = audio.crop(file, chunk)
+            output = self.slide(waveform, sample_rate, hook=hook)
+            frames = output.sliding_window
+            shifted = SlidingWindow(start=chunk.start, duration=frames.duration, step=frames.step)
+            return SlidingWindowFeature(output.data, shifted)
+        if isinstance(chunk, Segment):
+            waveform, _ = audio.crop(file, chunk)
+        else:
+            waveform = torch.cat([audio.crop(file, c)[0] for c in chunk], dim=1)
+        return self.infer(waveform[None])[0]
+
     def slide(self, waveform: torch.Tensor, sample_rate: int, hook: Optional[Callable] = None,
               chunk_range: Optional[Tuple[int, int]] = None) -> SlidingWindowFeature:
         """waveform: (1, num_samples), host or device.  `chunk_range` restricts processing to chunks
@@ -90,11 +132,10 @@ class Inference(BaseInference):
         wav = waveform.to(self.model.device, torch.float32).contiguous().view(-1)
         if hook is not None:
             hook(completed=0, total=total)
-        engine = self.model.engine
         want_logp = self.skip_conversion
         sub = wav[begin * step_size:]
-        logp, ml = engine.forward_strided(sub, step_size, end - begin, window_size,
-                                          want_logp=want_logp, want_multilabel=not want_logp)
+        logp, ml = self._forward(sub, step_size, end - begin, window_size,
+                                 want_logp=want_logp, want_multilabel=not want_logp)
         self.last_device_output = ml
         self.last_enqueued = time.perf_counter()     # host clock when the launch group was queued
         outputs = (logp if want_logp else ml.to(torch.float32)).cpu().numpy()
@@ -131,8 +172,7 @@ class Inference(BaseInference):
         waveform, sample_rate = Audio(self.model.audio.sample_rate, mono="downmix", device=self.device)(file)
         if self.window == "sliding":
             return self.slide(waveform, sample_rate, hook=hook)
-        out = self.model(waveform[None].to(self.model.device))
-        return out[0].cpu().numpy()
+        return self.infer(waveform[None])[0]            # core/inference.py:412-418
 
     # ---------------------------------------------------------------------------------------
     @staticmethod

@@ -128,3 +128,14 @@ def test_file_crop_bounds(wav_file):
     assert wav.shape[1] == sr and torch.all(wav[0, 8000:] == 0)
     wav, _ = loader.crop({"audio": str(path), "channel": 1}, Segment(0.0, 0.25))
     assert torch.allclose(wav[0], torch.from_numpy(data[:4000, 1].astype(np.float32) / 32768.0), atol=1e-7)
+
+
+def test_power_normalize_and_duration(wav_file):                   # core/io.py:134-151, 266-290
+    path, sr, data = wav_file
+    x = torch.randn(3, 2, 8000) * 7.0
+    y = Audio.power_normalize(x)
+    assert torch.allclose(y.square().mean(dim=-1), torch.ones(3, 2), atol=1e-4)
+    assert Audio().get_duration(path) == data.shape[0] / sr
+    assert Audio().get_duration({"waveform": torch.zeros(1, 24000), "sample_rate": 16000}) == 1.5
+    with open(path, "rb") as f:
+        assert Audio().get_duration(f) == 2.0 and f.tell() == 0
