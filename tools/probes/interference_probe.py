@@ -4,7 +4,6 @@ usage: sh tools/probes/build.sh && python tools/probes/interference_probe.py"""
 import ctypes as C, os, sys, time
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
-import numpy as np
 import torch
 import pyannote_audio_amd.ffi as ffi
 from pyannote_audio_amd.weights import winograd_pack, winograd_weights
