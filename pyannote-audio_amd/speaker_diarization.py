@@ -120,6 +120,7 @@ class SpeakerDiarization(Pipeline):
         self.clustering = Clustering[clustering].value(**self._clustering_kwargs(clustering, metric))
         self._expects_num_speakers = self.clustering.expects_num_clusters
         self.timings: dict = {}
+        self.batch_timeline: list = []       # apply_batch: host-clock stage boundaries per file
         self._last_front: Optional[_FrontEnd] = None
 
     def _clustering_kwargs(self, name: str, metric: str) -> dict:

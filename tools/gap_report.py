@@ -2,6 +2,10 @@
 hardware queue, the busy time and the largest gaps between consecutive kernels (development aid for the
 pipelined `apply_batch`: the kernel time of a file's front end sums to less than the measured step).
 
+CAVEAT (learned in round 2): under rocprofv3 the dispatches of different HIP streams are largely
+serialised, so the gaps of a two-stream run (apply_batch) are NOT the gaps of the un-profiled run -- compare
+per-kernel durations (tools/trace_table.py) and host timestamps (`batch_timeline_s` of the bench line) instead.
+
 usage: python tools/gap_report.py <dir-or-kernel_trace.csv> [min_gap_ms]"""
 import csv
 import os
