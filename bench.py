@@ -287,7 +287,8 @@ def bench_stage(args, pipeline, device, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10,
+                    help="timed files per GPU (the stream is pipelined: the last file's back end is exposed once)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--hours", type=float, default=1.0, help="audio hours per GPU and step")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="audio seconds of the CPU baseline")
