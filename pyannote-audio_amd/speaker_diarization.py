@@ -24,7 +24,7 @@ import time
 import warnings
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
-from typing import Any, Callable, Iterable, Iterator, List, Optional, Tuple
+from typing import Any, Callable, Iterable, Iterator, List, Mapping, Optional, Tuple
 
 import numpy as np
 import torch
@@ -365,13 +365,18 @@ class SpeakerDiarization(Pipeline):
                                speaker_embeddings=centroids)
         return output.speaker_diarization if self.legacy else output
 
-    def _speaker_bounds(self, num_speakers, min_speakers, max_speakers, kwargs):
+    def _speaker_bounds(self, num_speakers, min_speakers, max_speakers, kwargs, file=None):
+        """(:565-590) unknown keyword arguments are ignored with a warning; a clustering that needs the
+        number of speakers (KMeans) takes it from the file's reference annotation when it has one."""
         if len(kwargs) > 0:
             warnings.warn(f"Ignoring unexpected keyword arguments: {', '.join(list(kwargs.keys()))}")
         num_speakers, min_speakers, max_speakers = set_num_speakers(
             num_speakers=num_speakers, min_speakers=min_speakers, max_speakers=max_speakers)
         if self._expects_num_speakers and num_speakers is None:
-            raise ValueError(f"num_speakers must be provided when using {self.klustering} clustering")
+            if isinstance(file, Mapping) and "annotation" in file:
+                num_speakers = len(file["annotation"].labels())   # the bounds stay (1, inf), as in the reference
+            else:
+                raise ValueError(f"num_speakers must be provided when using {self.klustering} clustering")
         return num_speakers, min_speakers, max_speakers
 
     # ---------------------------------------------------------------------------------------- apply
@@ -380,7 +385,7 @@ class SpeakerDiarization(Pipeline):
               hook: Optional[Callable] = None, **kwargs):
         """speaker_diarization.py:530-784"""
         num_speakers, min_speakers, max_speakers = self._speaker_bounds(num_speakers, min_speakers,
-                                                                        max_speakers, kwargs)
+                                                                        max_speakers, kwargs, file=file)
         hook = self.setup_hook(file, hook=hook)
         self._require_device()
         front = self._front_end(file, hook)

@@ -5,6 +5,8 @@ pipeline classes resolved by dotted name exactly as the reference resolves plugi
 (core/pipeline.py:271-278: `token` and `cache_dir` are always injected into the constructor)."""
 import os
 
+import numpy as np
+
 import pytest
 import yaml
 
@@ -147,3 +149,23 @@ def test_list_call_contract(tmp_path):
     assert [f["uri"] for f, _ in out] == ["a", "b"] and all(o is None for _, o in out)
     with pytest.raises(ValueError, match="distinct URIs"):
         list(p([files[0], dict(files[0])]))
+
+
+def test_speaker_bounds_contract(pipeline_dir):
+    """speaker_diarization.py:565-590: unknown keyword arguments warn, a clustering that needs the number of
+    speakers takes it from the file's reference annotation (bounds untouched) or raises."""
+    import pyannote_audio_amd as pa
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir)
+    assert pipeline._speaker_bounds(None, None, None, {}) == (None, 1, np.inf)
+    assert pipeline._speaker_bounds(None, 2, 2, {}) == (2, 2, 2)
+    with pytest.warns(UserWarning, match="Ignoring unexpected keyword arguments: foo"):
+        pipeline._speaker_bounds(3, None, None, {"foo": 1})
+    with pytest.raises(ValueError):
+        pipeline._speaker_bounds(None, 3, 2, {})
+    pipeline._expects_num_speakers = True                      # what KMeansClustering declares
+    with pytest.raises(ValueError, match="num_speakers must be provided"):
+        pipeline._speaker_bounds(None, None, None, {}, file={"uri": "x"})
+    reference = pa.Annotation(uri="x")
+    reference[pa.Segment(0, 1), "a"] = "alice"
+    reference[pa.Segment(1, 2), "b"] = "bob"
+    assert pipeline._speaker_bounds(None, None, None, {}, file={"uri": "x", "annotation": reference}) == (2, 1, np.inf)
