@@ -11,7 +11,8 @@ from .model import (Model, PyanNet, WeSpeakerResNet34, WeSpeakerResNet152, WeSpe
                     WeSpeakerResNet293, Specifications, Problem, Resolution)  # noqa: E402,F401
 from .pipeline import Pipeline  # noqa: E402,F401
 from .inference import Inference  # noqa: E402,F401
-from .clustering import AgglomerativeClustering, Clustering, KMeansClustering, VBxClustering
+from .clustering import (AgglomerativeClustering, Clustering, KMeansClustering, OracleClustering,  # noqa: E402,F401
+                         VBxClustering)
 from .plda import PLDA  # noqa: E402,F401
 from .speaker_verification import PretrainedSpeakerEmbedding  # noqa: E402,F401
 from .speaker_diarization import SpeakerDiarization, DiarizeOutput  # noqa: E402,F401

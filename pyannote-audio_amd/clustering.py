@@ -417,14 +417,39 @@ class VBxClustering(BaseClustering):
         return hard.reshape(embeddings.shape[:2]), soft, centroids
 
 
-def _not_built(name):
-    class _Missing(BaseClustering):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(
-                f"{name} needs the reference annotation of every file (pyannote.database protocol): "
-                "outside the inference hot path (SURVEY.md section 8f)")
-    _Missing.__name__ = name
-    return _Missing
+class OracleClustering(BaseClustering):
+    """Clusters with the answer sheet (clustering.py:672-756): every chunk's local speakers are mapped onto
+    the reference speakers by the cost-minimising permutation between the model's segmentation and the
+    reference annotation discretised on the same chunk / frame grid.  Needs `file["annotation"]`; no
+    embeddings are involved in the assignment (centroids are computed when they are given)."""
+
+    expects_num_clusters = True
+
+    def __call__(self, embeddings: Optional[np.ndarray] = None,
+                 segmentations: Optional[SlidingWindowFeature] = None, file=None, frames=None, **kwargs):
+        from .annotation_frames import oracle_segmentation
+        from .permutation import permutate
+        num_chunks, num_frames, num_speakers = segmentations.data.shape
+        oracle = oracle_segmentation(file, segmentations.sliding_window, frames=frames)
+        file["oracle_segmentations"] = oracle
+        num_clusters = oracle.data.shape[2]
+        common = min(num_frames, oracle.data.shape[1])
+        seg, ref = segmentations.data[:, :common], oracle.data[:, :common]
+        hard = np.full((num_chunks, num_speakers), -2, dtype=np.int8)
+        soft = np.zeros((num_chunks, num_speakers, num_clusters))
+        for c in range(min(num_chunks, ref.shape[0])):     # the zero-padded last chunk has no reference chunk
+            _, (permutation,) = permutate(ref[c][np.newaxis], seg[c])
+            for cluster, speaker in enumerate(permutation):
+                if speaker is not None:
+                    hard[c, speaker] = cluster
+                    soft[c, speaker, cluster] = 1.0
+        if embeddings is None:
+            return hard, soft, None
+        train, chunk_idx, speaker_idx = self.filter_embeddings(
+            embeddings, segmentations=SlidingWindowFeature(seg, segmentations.sliding_window))
+        train_clusters = hard[chunk_idx, speaker_idx]
+        centroids = np.vstack([np.mean(train[train_clusters == k], axis=0) for k in range(num_clusters)])
+        return hard, soft, centroids
 
 
 class Clustering(Enum):
@@ -432,4 +457,4 @@ class Clustering(Enum):
     AgglomerativeClustering = AgglomerativeClustering
     KMeansClustering = KMeansClustering
     VBxClustering = VBxClustering
-    OracleClustering = _not_built("OracleClustering")
+    OracleClustering = OracleClustering

@@ -320,6 +320,41 @@ if not HAVE_PYANNOTE_CORE:
         def label_duration(self, label) -> float:
             return sum(s.duration for s, _, l in self.itertracks(yield_label=True) if l == label)
 
+        def discretize(self, support: Optional[Segment] = None, resolution=0.01, labels: Optional[list] = None,
+                       duration: Optional[float] = None) -> "SlidingWindowFeature":
+            """(num_frames, num_labels) uint8 {0, 1}: label k is on in frame i when a segment of k, clipped to
+            `support`, covers the frame in the "center" sense of SlidingWindow.crop.  Restates
+            pyannote.core's Annotation.discretize (frames start at the support's start; `duration` fixes
+            the number of frames to round(duration / step); labels default to those inside the support)."""
+            segments = self._segments()
+            if support is None:
+                if not segments:
+                    raise ValueError("cannot discretize an empty annotation without `support`")
+                support = Segment(min(s.start for s in segments), max(s.end for s in segments))
+            inside = []
+            for segment, _, label in self.itertracks(yield_label=True):
+                clipped = segment & support
+                if clipped:
+                    inside.append((clipped, label))
+            if labels is None:
+                labels = sorted({label for _, label in inside}, key=str)
+            if isinstance(resolution, SlidingWindow):
+                frames = SlidingWindow(start=support.start, step=resolution.step, duration=resolution.duration)
+            else:
+                frames = SlidingWindow(start=support.start, step=resolution, duration=resolution)
+            if duration is None:
+                num_frames = frames.closest_frame(support.end) - frames.closest_frame(support.start)
+            else:
+                num_frames = int(round(duration / frames.step))
+            column = {label: k for k, label in enumerate(labels)}
+            data = np.zeros((max(num_frames, 0), len(labels)), dtype=np.uint8)
+            for clipped, label in inside:
+                if label not in column:
+                    continue
+                (first, stop), = frames.crop(clipped, mode="center", return_ranges=True)
+                data[max(0, first):min(stop, num_frames), column[label]] = 1
+            return SlidingWindowFeature(data, frames, labels=labels)
+
         def rename_labels(self, mapping: Optional[dict] = None, generator="string", copy: bool = True):
             if mapping is None:
                 gen = string_generator() if generator == "string" else itertools.count()

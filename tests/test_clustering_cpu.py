@@ -110,8 +110,7 @@ def test_kmeans_and_enum_members():
     assert hard.shape == (60, 3) and cen.shape == (3, 24) and set(np.unique(hard)) <= {0, 1, 2}
     with pytest.raises(ValueError):
         km.cluster(emb[:, 0].copy())
-    with pytest.raises(NotImplementedError):
-        pa.Clustering["OracleClustering"].value()
+    assert pa.Clustering["OracleClustering"].value is pa.OracleClustering
     with pytest.raises(ValueError, match="PLDA"):
         pa.VBxClustering().instantiate({"threshold": 0.6, "Fa": 0.07, "Fb": 0.8})(
             embeddings=emb, segmentations=SlidingWindowFeature(seg, CHUNKS))
