@@ -6,7 +6,7 @@ diarization.py:264-266 and signal.py:276-305, ~213 k iterations per audio-hour e
 array operations with the same tie-breaking and the same floating-point timestamps."""
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Mapping, Optional, Tuple
 
 import numpy as np
 
@@ -135,3 +135,43 @@ def to_annotation(discrete_diarization: SlidingWindowFeature, min_duration_on: f
     """diarization.py:188-218"""
     return Binarize(onset=0.5, offset=0.5, min_duration_on=min_duration_on,
                     min_duration_off=min_duration_off)(discrete_diarization)
+
+
+def cooccurrence(a: Annotation, b: Annotation, annotated=None) -> Tuple[list, list, np.ndarray]:
+    """(labels of a, labels of b, seconds during which label i of `a` and label j of `b` are both on) --
+    the co-occurrence matrix `a * b` of pyannote.core, optionally restricted to the `annotated` regions."""
+    la, lb = a.labels(), b.labels()
+    ia, ib = {l: i for i, l in enumerate(la)}, {l: j for j, l in enumerate(lb)}
+    regions = None if annotated is None else [(r.start, r.end) for r in annotated]
+    tb = [(s.start, s.end, ib[l]) for s, _, l in b.itertracks(yield_label=True)]
+    out = np.zeros((len(la), len(lb)))
+    for s, _, l in a.itertracks(yield_label=True):
+        for start, end, j in tb:
+            lo, hi = max(s.start, start), min(s.end, end)
+            if hi <= lo:
+                continue
+            if regions is None:
+                out[ia[l], j] += hi - lo
+            else:
+                out[ia[l], j] += sum(max(0.0, min(hi, r1) - max(lo, r0)) for r0, r1 in regions)
+    return la, lb, out
+
+
+def optimal_mapping(reference, hypothesis: Annotation, return_mapping: bool = False):
+    """Hypothesis labels renamed to the reference labels they overlap most with, one-to-one (Hungarian on the
+    co-occurrence durations; pairs that never overlap stay unmapped) -- pipelines/utils/diarization.py:104-148,
+    which delegates to pyannote.metrics' DiarizationErrorRate().optimal_mapping (not installed: restated,
+    unpinned).  `reference` may be the annotation or a file mapping with "annotation" [and "annotated"]."""
+    from scipy.optimize import linear_sum_assignment
+    annotated = None
+    if isinstance(reference, Mapping):
+        annotated = reference["annotated"] if "annotated" in reference else None
+        reference = reference["annotation"]
+    hyp_labels, ref_labels, together = cooccurrence(hypothesis, reference, annotated)
+    mapping = {}
+    if together.size:
+        for i, j in zip(*linear_sum_assignment(-together)):
+            if together[i, j] > 0:
+                mapping[hyp_labels[i]] = ref_labels[j]
+    mapped = hypothesis.rename_labels(mapping=mapping)
+    return (mapped, mapping) if return_mapping else mapped

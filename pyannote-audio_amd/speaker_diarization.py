@@ -35,7 +35,7 @@ from . import parallel
 from .clustering import Clustering
 from .audio import Audio, AudioFile
 from .core import Annotation, SlidingWindow, SlidingWindowFeature
-from .diarization import set_num_speakers, to_annotation
+from .diarization import optimal_mapping, set_num_speakers, to_annotation
 from .inference import Inference
 from .model import Model
 from .pipeline import ParamDict, Pipeline, Uniform
@@ -343,10 +343,11 @@ class SpeakerDiarization(Pipeline):
         gap = self.segmentation.min_duration_off
         diarization = to_annotation(regular, min_duration_on=0.0, min_duration_off=gap)
         exclusive_diarization = to_annotation(exclusive, min_duration_on=0.0, min_duration_off=gap)
-        # cluster ids -> SPEAKER_00, SPEAKER_01, ... in labels() order (:730-737); the mapping onto a
-        # reference annotation (:718-729) needs pyannote.metrics and is out of scope
+        # cluster ids -> SPEAKER_00, SPEAKER_01, ... in labels() order (:730-737) -- or, when the file comes
+        # with its reference annotation, -> the reference speakers they overlap most with (:718-729; output
+        # unchanged otherwise, it only makes error analysis easier)
         labels = diarization.labels()
-        names = dict(zip(labels, self.classes()))
+        names = self._label_names(file, diarization, labels)
         diarization = diarization.rename_labels(mapping=names)
         exclusive_diarization = exclusive_diarization.rename_labels(mapping=names)
         diarization.uri = exclusive_diarization.uri = file["uri"]
@@ -364,6 +365,12 @@ class SpeakerDiarization(Pipeline):
                                exclusive_speaker_diarization=exclusive_diarization,
                                speaker_embeddings=centroids)
         return output.speaker_diarization if self.legacy else output
+
+    def _label_names(self, file, diarization: Annotation, labels: list) -> dict:
+        if isinstance(file, Mapping) and "annotation" in file and file["annotation"]:
+            _, mapping = optimal_mapping(file["annotation"], diarization, return_mapping=True)
+            return {label: mapping.get(label, label) for label in labels}   # extra speakers keep their id
+        return dict(zip(labels, self.classes()))
 
     def _speaker_bounds(self, num_speakers, min_speakers, max_speakers, kwargs, file=None):
         """(:565-590) unknown keyword arguments are ignored with a warning; a clustering that needs the

@@ -8,7 +8,7 @@ import torch
 import pyannote_audio_amd as pa
 from oracle import pipeline as O
 from pyannote_audio_amd import diarization as D
-from pyannote_audio_amd.core import SlidingWindow, SlidingWindowFeature
+from pyannote_audio_amd.core import Segment, SlidingWindow, SlidingWindowFeature
 from pyannote_audio_amd.inference import Inference
 
 
@@ -213,3 +213,28 @@ def test_bottleneck_checkpoint_loader(tmp_path):
     pack = EmbeddingPack(net.state_dict(), torch.device("cpu"))
     assert pack.bottleneck and pack.num_blocks == (1, 2, 1, 1) and pack.struct.bottleneck == 1
     assert EmbeddingPack(basic.state_dict(), torch.device("cpu")).struct.bottleneck == 0
+
+
+def test_optimal_mapping_onto_reference_speakers():
+    """pipelines/utils/diarization.py:104-148 (pyannote.metrics' Hungarian mapper restated): hypothesis labels
+    take the name of the reference speaker they overlap most with, one-to-one; never-overlapping ones keep theirs."""
+    from pyannote_audio_amd.diarization import cooccurrence, optimal_mapping
+    ref = pa.Annotation(uri="r")
+    ref[Segment(0, 10), "_"] = "alice"
+    ref[Segment(10, 20), "_"] = "bob"
+    hyp = pa.Annotation(uri="h")
+    hyp[Segment(0, 9), "_"] = 0          # alice
+    hyp[Segment(9, 12), "_"] = 1         # 1 s of alice, 2 s of bob
+    hyp[Segment(12, 20), "_"] = 2        # bob
+    hyp[Segment(30, 31), "_"] = 3        # outside the reference
+    la, lb, m = cooccurrence(hyp, ref)
+    assert la == [0, 1, 2, 3] and lb == ["alice", "bob"]
+    assert np.allclose(m, [[9, 0], [1, 2], [0, 8], [0, 0]])
+    mapped, mapping = optimal_mapping(ref, hyp, return_mapping=True)
+    assert mapping == {0: "alice", 2: "bob"}
+    assert mapped.labels() == sorted([1, 3, "alice", "bob"], key=str)
+    # only the annotated region counts when the file says which part was annotated
+    file = {"annotation": ref, "annotated": [Segment(9, 12)]}
+    _, mapping = optimal_mapping(file, hyp, return_mapping=True)
+    assert mapping == {1: "bob"}         # inside [9, 12] only speaker 1 overlaps anybody (1 s alice, 2 s bob)
+    assert optimal_mapping(ref, pa.Annotation(uri="empty")).labels() == []
