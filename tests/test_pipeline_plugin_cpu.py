@@ -169,3 +169,20 @@ def test_speaker_bounds_contract(pipeline_dir):
     reference[pa.Segment(0, 1), "a"] = "alice"
     reference[pa.Segment(1, 2), "b"] = "bob"
     assert pipeline._speaker_bounds(None, None, None, {}, file={"uri": "x", "annotation": reference}) == (2, 1, np.inf)
+
+
+def test_label_names(pipeline_dir):
+    """speaker_diarization.py:716-737: SPEAKER_xx in labels() order, or the reference speakers when the file
+    carries its annotation (hypothesis speakers without a counterpart keep their cluster id)."""
+    import pyannote_audio_amd as pa
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir)
+    hyp = pa.Annotation(uri="h")
+    hyp[pa.Segment(0, 5), "_"] = 0
+    hyp[pa.Segment(5, 9), "_"] = 1
+    hyp[pa.Segment(20, 21), "_"] = 2
+    assert pipeline._label_names({"uri": "h"}, hyp, hyp.labels()) == {0: "SPEAKER_00", 1: "SPEAKER_01", 2: "SPEAKER_02"}
+    ref = pa.Annotation(uri="h")
+    ref[pa.Segment(0, 5), "_"] = "alice"
+    ref[pa.Segment(5, 10), "_"] = "bob"
+    assert pipeline._label_names({"uri": "h", "annotation": ref}, hyp, hyp.labels()) == {0: "alice", 1: "bob", 2: 2}
+    assert pipeline._label_names({"uri": "h", "annotation": pa.Annotation()}, hyp, hyp.labels())[0] == "SPEAKER_00"
