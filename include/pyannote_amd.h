@@ -168,7 +168,13 @@ int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, con
                    float* out, void* stream);
 int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, const float* shift,
                const float* R, float* Y, int cout, int stride, int relu, void* stream);
-/* the same stride-1 convolution through Winograd F(2x2,3x3); U: [16][cout][cin] = G g G^T, xi = 4a + b */
+/* the same stride-1 convolution through Winograd F(2x2,3x3).  U is NOT a plain [16][cout][cin] array: it is
+ * G g G^T packed as one contiguous 32-KB slab per (32-cout slice, 16-cin stage),
+ * [cout/32][cin/16][row = 32 xi + (cout % 32)][slot][4] with xi = 4a + b and channel quad q of the stage at
+ * slot (q + 2 ((row >> 2) & 1)) & 3 -- build it with pa_winograd_pack_host (cout % 32 == 0, cin % 16 == 0). */
+int pa_winograd_pack_host(const float* conv_weight /* (cout, cin, 3, 3), resnet.py:92-107 */,
+                          const float* bn_scale /* (cout) gamma / sqrt(var + eps), or NULL */, int cout, int cin,
+                          float* U_slabs /* HOST buffer, 16 * cout * cin floats */);
 int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                     const float* R, float* Y, int cout, int relu, void* stream);
 int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream);

@@ -83,9 +83,8 @@ def _frame_targets(act_chunk: np.ndarray, num_frames: int, rf_size=991, rf_step=
     return cls
 
 
-def calibrated_pyannet(seed: int = 1234, num_layers: int = 4, calib_seconds: float = 120.0,
-                       chunk_s: float = 10.0, ridge: float = 1e-2, gain: float = 6.0) -> PyanNet:
-    """seeded PyanNet whose classifier is a ridge read-out fitted on a synthetic conversation."""
+def uncalibrated_pyannet(seed: int = 1234, num_layers: int = 4) -> PyanNet:
+    """The deterministic part of `calibrated_pyannet`: seeded weights, recurrent / linear stacks scaled."""
     model = seeded_pyannet(seed=seed, num_layers=num_layers, classifier_gain=1.0)
     # default-initialised LSTM/Linear stacks barely react to their input (feature std ~5e-4): scale
     # them so that the read-out has something time-varying to work with
@@ -97,6 +96,27 @@ def calibrated_pyannet(seed: int = 1234, num_layers: int = 4, calib_seconds: flo
                 p.mul_(2.0)
         for lin in model.linear:
             lin.weight.mul_(3.0)
+    return model
+
+
+def models_from_readout(classifier_weight, classifier_bias, seg1_bias, seg_seed: int = 1234,
+                        emb_seed: int = 4321):
+    """(PyanNet, WeSpeakerResNet34) with a STORED read-out instead of a fitted one: the fit is a float64
+    solve whose last bits depend on the host's BLAS, so golden vectors carry the fitted parameters
+    (tests/golden/reference_v1.npz) and every box rebuilds bit-identical checkpoints from them."""
+    seg = uncalibrated_pyannet(seed=seg_seed)
+    emb = seeded_wespeaker(seed=emb_seed)
+    with torch.no_grad():
+        seg.classifier.weight.copy_(torch.as_tensor(classifier_weight))
+        seg.classifier.bias.copy_(torch.as_tensor(classifier_bias))
+        emb.resnet.seg_1.bias.copy_(torch.as_tensor(seg1_bias))
+    return seg, emb
+
+
+def calibrated_pyannet(seed: int = 1234, num_layers: int = 4, calib_seconds: float = 120.0,
+                       chunk_s: float = 10.0, ridge: float = 1e-2, gain: float = 6.0) -> PyanNet:
+    """seeded PyanNet whose classifier is a ridge read-out fitted on a synthetic conversation."""
+    model = uncalibrated_pyannet(seed=seed, num_layers=num_layers)
     wav, act = synth_conversation(calib_seconds, seed=seed + 1)
     N = int(chunk_s * 16000)
     starts = list(range(0, wav.shape[1] - N + 1, N // 2))

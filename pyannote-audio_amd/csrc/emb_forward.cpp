@@ -15,6 +15,7 @@ struct EmbPlan {
   int B, N, T, F, S;
   int Hs[5], Ws[5];  // spatial dims after stem (index 0) and after each layer
   size_t fbank, act[4], stats, total, act_elems;
+  size_t t2_off, gather_off;  // Bottleneck: sub-regions of act[3] (t1 at 0)
 };
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
@@ -44,7 +45,25 @@ bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p) {
   p->act_elems = (size_t)B * p->Hs[0] * p->Ws[0] * w->planes[0] * ex;
   // BasicBlock: 3 ping-pong buffers; Bottleneck: block input / output / shortcut at 4 x planes channels
   // (3 buffers) + the two planes-wide intermediates and the stride-2 gather (a 4th buffer, split in 3)
-  for (int i = 0; i < (w->bottleneck ? 4 : 3); ++i) p->act[i] = take(p->act_elems);
+  for (int i = 0; i < 3; ++i) p->act[i] = take(p->act_elems);
+  p->t2_off = p->gather_off = 0;
+  if (w->bottleneck) {
+    // sub-regions sized from the real block dimensions (odd maps: Ho = ceil(H / 2), so Ho * Wo > H * W / 4)
+    size_t t1 = 0, t2 = 0, g = 0;
+    int cin = w->planes[0];
+    for (int l = 0; l < w->num_layers; ++l) {
+      const size_t planes = w->planes[l];
+      const size_t in_px = (size_t)B * p->Hs[l == 0 ? 1 : l] * p->Ws[l == 0 ? 1 : l];
+      const size_t out_px = (size_t)B * p->Hs[l + 1] * p->Ws[l + 1];
+      t1 = t1 > in_px * planes ? t1 : in_px * planes;  // first block of the layer runs its 1x1 at input size
+      t2 = t2 > out_px * planes ? t2 : out_px * planes;
+      if (l > 0) g = g > out_px * cin ? g : out_px * cin;
+      cin = 4 * (int)planes;
+    }
+    p->t2_off = align64(t1);
+    p->gather_off = p->t2_off + align64(t2);
+    p->act[3] = take(p->gather_off + align64(g));
+  }
   const int L = w->num_layers;
   p->stats = take((size_t)B * p->S * 2 * w->planes[L - 1] * ex * p->Hs[L]);
   p->total = o;
@@ -110,10 +129,8 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
     // strided direct kernel) -> 1x1 + shortcut + ReLU fused into the last GEMM's epilogue
     float* nxt = f1;                 // block output
     float* sc = f2;                  // shortcut branch
-    // 4th buffer = t1 (<= act_elems / 2: the 1x1 of a stride-2 block runs at the INPUT resolution with
-    // twice the planes) | t2 (<= act_elems / 4) | stride-2 gather (<= act_elems / 4)
+    // 4th buffer = t1 | t2 | stride-2 gather, each sized in make_plan from the largest block that uses it
     float* tmp = ws + p.act[3];
-    const size_t quarter = p.act_elems / 4;
     for (int l = 0; l < w->num_layers; ++l) {
       const int planes = w->planes[l], cout = 4 * planes;
       for (int i = 0; i < w->num_blocks[l]; ++i, ++blk) {
@@ -125,8 +142,8 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         const int H = stride == 2 ? p.Hs[l] : p.Hs[l + 1], W = stride == 2 ? p.Ws[l] : p.Ws[l + 1];
         const int Ho = p.Hs[l + 1], Wo = p.Ws[l + 1];
         float* t1 = tmp;
-        float* t2 = tmp + 2 * quarter;
-        float* G = tmp + 3 * quarter;
+        float* t2 = tmp + p.t2_off;
+        float* G = tmp + p.gather_off;
         RUN(pa_gemm_tn_ex(cur, cin, w->blk_w1[blk], cin, w->blk_shift1[blk], nullptr, t1, planes, B * H * W,
                           planes, cin, 2, 0, stream));
         if (stride == 1 && w->blk_u2[blk] != nullptr)

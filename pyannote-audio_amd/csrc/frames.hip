@@ -1,3 +1,4 @@
+// hipcc-flags: -ffp-contract=off
 // Frame-domain stages of the diarization pipeline on gfx950: everything between the per-chunk hard
 // segmentations and the per-frame speaker decisions.  These are the reference's Python hot loops
 // #2, #4 and #5: ~213 k global frames per audio-hour walked in the interpreter.

@@ -134,3 +134,45 @@ size_t pa_prof_report(char* buf, size_t cap) {
   return s.size() + 1;
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+// HOST helper: the weight image pa_conv3x3_wino expects, from the reference's conv weight.
+// U = G g G^T (Winograd F(2x2,3x3), float64 arithmetic, BatchNorm scale folded per output channel), then
+// packed as one contiguous 32-KB slab per (32-cout slice, 16-cin stage): [cout/32][cin/16][row = 32 xi + n]
+// [slot][4] with xi = 4a + b, n = cout % 32, and channel quad q of the stage at physical slot
+// (q + 2 ((row >> 2) & 1)) & 3 (the bank-conflict-free LDS image of emb_winograd.hip, so that the kernel's
+// LDS-DMA is a linear stream).  Same result as weights.winograd_pack(winograd_weights(w * scale)).
+// ---------------------------------------------------------------------------------------------
+extern "C" int pa_winograd_pack_host(const float* conv_weight, const float* bn_scale, int cout, int cin,
+                                     float* U_slabs) {
+  if (cout <= 0 || cin <= 0 || cout % 32 != 0 || cin % 16 != 0 || !conv_weight || !U_slabs) {
+    pa::set_error("pa_winograd_pack_host: cout %% 32 == 0 and cin %% 16 == 0 required (got %d, %d)", cout, cin);
+    return 3;
+  }
+  static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  const int stages = cin / 16;
+  for (int o = 0; o < cout; ++o) {
+    for (int i = 0; i < cin; ++i) {
+      double g[3][3];
+      for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+          // the product kernel folds BN in float32 (weights.py: conv.weight * scale[:, None, None, None])
+          const float folded = bn_scale ? conv_weight[((size_t)o * cin + i) * 9 + p * 3 + q] * bn_scale[o]
+                                        : conv_weight[((size_t)o * cin + i) * 9 + p * 3 + q];
+          g[p][q] = (double)folded;
+        }
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+          double u = 0.0;
+          for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < 3; ++q) u += G[a][p] * g[p][q] * G[b][q];
+          const int xi = 4 * a + b, row = 32 * xi + (o % 32);
+          const int quad = (i % 16) / 4, slot = (quad + 2 * ((row >> 2) & 1)) & 3;
+          const size_t slab = ((size_t)(o / 32) * stages + i / 16) * 512 * 16;
+          U_slabs[slab + (size_t)row * 16 + slot * 4 + (i % 4)] = (float)u;
+        }
+    }
+  }
+  return 0;
+}
+

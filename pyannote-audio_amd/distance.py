@@ -15,13 +15,20 @@ from scipy.spatial.distance import pdist as _scipy_pdist
 from . import ffi
 
 def _use_gpu(device, n: int) -> bool:
-    """GPU kernels whenever the clustering object lives on a GPU (pipeline.to(cuda)); a clustering
-    object used stand-alone on the host (device None / cpu) calls SciPy, i.e. the reference's own
-    implementation.  A missing kernel on a GPU device is an error, never a silent downgrade."""
-    if device is None or getattr(device, "type", None) != "cuda" or n < 2:
+    """GPU kernels whenever the clustering object lives on a GPU (`pipeline.to(cuda)`).  There is no
+    silent downgrade: an object that was never placed (device None) RAISES, and a missing library on a
+    GPU device raises.  Only a clustering object that its user EXPLICITLY put on the host --
+    `clustering.to(torch.device("cpu"))`, stand-alone use outside the pipeline (the pipeline itself refuses
+    to run there: SpeakerDiarization._require_device) -- calls SciPy, i.e. the reference's own implementation
+    of these two functions; the CPU suite uses that to check the host-side cluster logic."""
+    kind = getattr(device, "type", None)
+    if kind == "cuda":
+        ffi.require_gpu()
+        return n >= 2
+    if kind == "cpu":
         return False
-    ffi.require_gpu()
-    return True
+    raise RuntimeError("clustering distances: no device set -- move the pipeline / clustering object to an "
+                       "MI355X with .to(torch.device('cuda')); this package has no implicit CPU path")
 
 
 @ffi.on_device(lambda X, device=None: device)

@@ -48,10 +48,11 @@ class PLDA:
         return self
 
     def _tensors(self, device):
-        if not self._dev:
+        key = (str(device), int(self.lda_dimension))
+        if self._dev.get("key") != key:
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)  # noqa: E731
             self._dev = {"mean1": up(self.mean1), "lda": up(self.lda), "mean2": up(self.mean2),
-                         "mu": up(self.plda_mu), "trT": up(self._tr[: self.lda_dimension].T)}
+                         "mu": up(self.plda_mu), "trT": up(self._tr[: self.lda_dimension].T), "key": key}
         return self._dev
 
     def transform_device(self, embeddings: np.ndarray, device: torch.device) -> torch.Tensor:

@@ -112,6 +112,8 @@ class SpeakerDiarization(Pipeline):
         self.segmentation = ParamDict(**tunables)
 
         metric = "not_applicable"
+        self._embedding = None
+        self._audio = Audio(sample_rate=seg_model.audio.sample_rate, mono="downmix")
         if clustering != "OracleClustering":
             self._embedding = PretrainedSpeakerEmbedding(self.embedding, token=token,
                                                          cache_dir=cache_dir)
@@ -131,8 +133,7 @@ class SpeakerDiarization(Pipeline):
 
     def to(self, device: torch.device):
         super().to(device)
-        if hasattr(self, "_audio"):
-            self._audio.device = device      # the front door resamples on the pipeline's GPU
+        self._audio.device = device          # the front door resamples on the pipeline's GPU
         return self
 
     @property
@@ -286,6 +287,11 @@ class SpeakerDiarization(Pipeline):
                           count=count, marks=marks, enqueued=enqueued)
         if np.nanmax(count.data) == 0.0:
             return front                       # nobody speaks: no embeddings (:617-629)
+        if self._embedding is None:            # OracleClustering: no embeddings (:631-636)
+            active, clean = frame_ops.chunk_stats(dev_seg)
+            front.active, front.clean = active.cpu().numpy(), clean.cpu().numpy()
+            self._last_front = front
+            return front
 
         if dev_emb is None:
             dev_emb, active, clean, batches = self._embed(waveform, dev_seg, chunks, 0,
@@ -308,7 +314,8 @@ class SpeakerDiarization(Pipeline):
     def _empty_output(self, file: dict):
         output = DiarizeOutput(speaker_diarization=Annotation(uri=file["uri"]),
                                exclusive_speaker_diarization=Annotation(uri=file["uri"]),
-                               speaker_embeddings=np.zeros((0, self._embedding.dimension)))
+                               speaker_embeddings=np.zeros(
+                                   (0, self._embedding.dimension if self._embedding is not None else 0)))
         return output.speaker_diarization if self.legacy else output
 
     def _cluster_one(self, front: _FrontEnd, num_speakers, min_speakers, max_speakers):
@@ -413,18 +420,41 @@ class SpeakerDiarization(Pipeline):
         `joint_clustering=True`: ONE clustering over the embeddings of all files (of all ranks when
         torch.distributed is initialised and `parallel.set_shard` was not used to split single files):
         speakers get the same label in every file (BASELINE.json configs[4])."""
-        bounds = self._speaker_bounds(num_speakers, min_speakers, max_speakers, kwargs)
-        device = self._require_device()
         files = [Audio.validate_file(f) for f in files]
+        batch_level = {"num_speakers": num_speakers, "min_speakers": min_speakers,
+                       "max_speakers": max_speakers, **kwargs}
+        batch_level = {k: v for k, v in batch_level.items() if v is not None}
         if joint_clustering:
-            yield from self._apply_jointly(files, bounds, hook, device)
+            # one clustering for all files: only batch-level bounds make sense
+            ignored = [f["uri"] for f in files if f.get("pipeline_kwargs")]
+            if ignored:
+                warnings.warn("joint_clustering=True ignores the `pipeline_kwargs` of "
+                              f"{', '.join(map(str, ignored))}")
+            bounds = self._speaker_bounds(num_speakers, min_speakers, max_speakers, kwargs)
+            yield from self._apply_jointly(files, bounds, hook, self._require_device())
             return
-        num_speakers, min_speakers, max_speakers = bounds
+
+        def bounds_of(file) -> tuple:
+            """core/pipeline.py:583 applies a file as `apply(file, **file["pipeline_kwargs"], **kwargs)`:
+            each file keeps its own num/min/max_speakers (a name given both ways is a TypeError there too)."""
+            own = dict(file.get("pipeline_kwargs", {}))
+            both = set(own) & set(batch_level)
+            if both:
+                raise TypeError(f"apply() got multiple values for keyword argument {sorted(both)[0]!r}")
+            merged = {**batch_level, **own}
+            known = {k: merged.pop(k, None) for k in ("num_speakers", "min_speakers", "max_speakers")}
+            merged.pop("hook", None)
+            return self._speaker_bounds(known["num_speakers"], known["min_speakers"], known["max_speakers"],
+                                        merged, file=file)
+
+        all_bounds = [bounds_of(f) for f in files]      # (raises before any GPU work, like a bad call would)
+        device = self._require_device()
         side = torch.cuda.Stream(device=device)
 
-        def tail(front: _FrontEnd, file_hook: Callable):
+        def tail(front: _FrontEnd, file_hook: Callable, bounds: tuple):
             if front.silent:
                 return self._empty_output(front.file)
+            num_speakers, min_speakers, max_speakers = bounds
             with torch.cuda.device(device), torch.cuda.stream(side):
                 hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
                 out = self._back_end(front, hard, centroids, min_speakers, max_speakers, file_hook)
@@ -439,15 +469,15 @@ class SpeakerDiarization(Pipeline):
         t_batch = time.perf_counter()
         self.batch_timeline = []               # per file: host-clock offsets (s) of the stage boundaries
 
-        def tail_timed(front: _FrontEnd, file_hook: Callable, line: dict):
+        def tail_timed(front: _FrontEnd, file_hook: Callable, line: dict, bounds: tuple):
             line["tail_start"] = time.perf_counter() - t_batch
-            out = tail(front, file_hook)
+            out = tail(front, file_hook, bounds)
             line["tail_done"] = time.perf_counter() - t_batch
             return out
 
         with ThreadPoolExecutor(max_workers=1) as pool:
             in_flight = None
-            for file in files:
+            for file, bounds in zip(files, all_bounds):
                 file_hook = self.setup_hook(file, hook=hook)
                 line = {"front_start": time.perf_counter() - t_batch}
                 front = self._front_end(file, file_hook)
@@ -457,7 +487,7 @@ class SpeakerDiarization(Pipeline):
                 if in_flight is not None:
                     yield in_flight[0], in_flight[1].result()
                 line["submit"] = time.perf_counter() - t_batch
-                in_flight = (file, pool.submit(tail_timed, front, file_hook, line))
+                in_flight = (file, pool.submit(tail_timed, front, file_hook, line, bounds))
             if in_flight is not None:
                 yield in_flight[0], in_flight[1].result()
 

@@ -46,6 +46,23 @@ def test_apply_batch_equals_sequential(pipeline_dir, gpu_device):
         pipeline([files[0], dict(files[1], uri=files[0]["uri"])])
 
 
+def test_apply_batch_honours_per_file_pipeline_kwargs(pipeline_dir, gpu_device):
+    """core/pipeline.py:583: every file of a list is applied with ITS `pipeline_kwargs`; a name given both
+    per file and per batch is the TypeError a double keyword is."""
+    import pyannote_audio_amd as pa
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir).to(gpu_device)
+    files = _files([(33.0, 5), (27.3, 8), (21.0, 2)])
+    files[0]["pipeline_kwargs"] = {"num_speakers": 1}
+    files[1]["pipeline_kwargs"] = {"min_speakers": 3, "max_speakers": 4}
+    want = [pipeline(copy.copy(f)) for f in files]
+    got = [out for _, out in pipeline(files)]
+    for out, ref in zip(got, want):
+        assert _turns(out.speaker_diarization) == _turns(ref.speaker_diarization)
+    assert len(got[0].speaker_diarization.labels()) == 1
+    with pytest.raises(TypeError, match="multiple values"):
+        list(pipeline(files, num_speakers=2))
+
+
 def _joint_reference(art, uris):
     """oracle clustering on the concatenation + per-file reconstruction"""
     from oracle import pipeline as op

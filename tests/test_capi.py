@@ -36,6 +36,30 @@ def test_frame_arithmetic_entry_points():
     assert lib.pa_emb_num_fbank_frames(399) == 0
 
 
+def test_winograd_pack_host_matches_python_packer():
+    """include/pyannote_amd.h: `pa_conv3x3_wino` takes the slab image, not [16][cout][cin]; the header's
+    host-side packer (what a C / C++ caller uses) equals weights.winograd_pack(winograd_weights(w * scale))."""
+    import numpy as np
+    import torch
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.weights import winograd_pack, winograd_weights
+    lib = ffi.load()
+    f32p = ctypes.POINTER(ctypes.c_float)
+    lib.pa_winograd_pack_host.argtypes = [f32p, f32p, ctypes.c_int, ctypes.c_int, f32p]
+    g = torch.Generator().manual_seed(0)
+    for cout, cin in ((32, 32), (64, 32), (128, 128)):
+        w = torch.randn(cout, cin, 3, 3, generator=g)
+        scale = 0.5 + torch.rand(cout, generator=g)
+        want = winograd_pack(winograd_weights(w * scale.view(-1, 1, 1, 1))).numpy().reshape(-1)
+        got = np.full(16 * cout * cin, np.nan, dtype=np.float32)
+        wn, sn = np.ascontiguousarray(w.numpy()), np.ascontiguousarray(scale.numpy())
+        rc = lib.pa_winograd_pack_host(wn.ctypes.data_as(f32p), sn.ctypes.data_as(f32p), cout, cin,
+                                       got.ctypes.data_as(f32p))
+        assert rc == 0 and not np.isnan(got).any()
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert lib.pa_winograd_pack_host(wn.ctypes.data_as(f32p), None, 48, 16, got.ctypes.data_as(f32p)) == 3
+
+
 def test_struct_layout_matches_header():
     """ctypes mirror of pa_seg_weights / pa_emb_weights has the size the C compiler gives."""
     import subprocess, tempfile

@@ -5,6 +5,7 @@ forced-number search (clustering.py:405-451) that the product answers from ONE s
 import warnings
 
 import numpy as np
+import torch
 import pytest
 from scipy.cluster.hierarchy import fcluster, linkage
 
@@ -79,7 +80,7 @@ def _data(C, K, noise, seed, D_=24, S=3, F=40):
 @pytest.mark.parametrize("min_size,threshold", [(12, 0.7045654963945799), (3, 0.4), (1, 1.1)])
 def test_agglomerative_matches_oracle(C, K, noise, seed, kw, min_size, threshold):
     emb, seg = _data(C, K, noise, seed)
-    clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
+    clu = pa.AgglomerativeClustering(metric="cosine").to(torch.device("cpu")).instantiate(
         {"method": "centroid", "min_cluster_size": min_size, "threshold": threshold})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -94,7 +95,7 @@ def test_agglomerative_matches_oracle(C, K, noise, seed, kw, min_size, threshold
 def test_other_linkage_methods_and_metrics_match_oracle():
     emb, seg = _data(80, 4, 0.2, 9)
     for method in ("average", "ward", "complete"):
-        clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
+        clu = pa.AgglomerativeClustering(metric="cosine").to(torch.device("cpu")).instantiate(
             {"method": method, "min_cluster_size": 5, "threshold": 0.8})
         hard, _, cen = clu(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS))
         rh, _, rc = O.clustering(emb.copy(), seg, method=method, threshold=0.8, min_cluster_size=5)
@@ -105,7 +106,7 @@ def test_kmeans_and_enum_members():
     assert set(pa.Clustering.__members__) == {"AgglomerativeClustering", "KMeansClustering",
                                               "VBxClustering", "OracleClustering"}
     emb, seg = _data(60, 3, 0.1, 5)
-    km = pa.KMeansClustering().instantiate({})
+    km = pa.KMeansClustering().to(torch.device("cpu")).instantiate({})
     hard, soft, cen = km(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS), num_clusters=3)
     assert hard.shape == (60, 3) and cen.shape == (3, 24) and set(np.unique(hard)) <= {0, 1, 2}
     with pytest.raises(ValueError):
@@ -114,3 +115,16 @@ def test_kmeans_and_enum_members():
     with pytest.raises(ValueError, match="PLDA"):
         pa.VBxClustering().instantiate({"threshold": 0.6, "Fa": 0.07, "Fb": 0.8})(
             embeddings=emb, segmentations=SlidingWindowFeature(seg, CHUNKS))
+
+
+def test_unplaced_clustering_object_raises():
+    """no implicit CPU path: a clustering object that was never moved to a device refuses to compute
+    (the SciPy route needs the explicit `.to(torch.device("cpu"))` used throughout this file)."""
+    rng = np.random.default_rng(0)
+    emb = rng.standard_normal((30, 3, 16)).astype(np.float32)
+    seg = SlidingWindowFeature(np.ones((30, 589, 3), dtype=np.float32), SlidingWindow(0.0, 10.0, 1.0))
+    seg.data[:, :, 1:] = 0
+    clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
+        {"method": "centroid", "min_cluster_size": 2, "threshold": 0.7})
+    with pytest.raises(RuntimeError, match="no device set"):
+        clu(embeddings=emb, segmentations=seg, min_clusters=1, max_clusters=np.inf)

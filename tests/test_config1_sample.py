@@ -57,31 +57,40 @@ def test_inference_on_sample_wav(pipeline_dir, synthetic_models, gpu_device):
     ref = op.slide(seg_o, wav, sr, 10.0, 1.0, 32)
     assert ref.shape == (21, 589, 3)
     chunks = wav.unfold(1, 160000, 16000).permute(1, 0, 2)
+    # (1) the float contract, outright: a default-gain seeded checkpoint on this real speech must meet
+    #     rtol 1e-4 / atol 1e-5 against the float32 oracle (tests/test_golden.py checks the same run against
+    #     the REFERENCE-generated vectors).
+    from oracle import seeded_pyannet
+    from pyannote_audio_amd.segmentation import SegmentationEngine
+    from pyannote_audio_amd.weights import SegmentationPack
+    plain = seeded_pyannet(seed=1234, num_layers=4)
+    eng = SegmentationEngine(SegmentationPack(plain.state_dict(), {"lstm": {"num_layers": 4}}, 7, 3, 2,
+                                              gpu_device))
+    with torch.inference_mode():
+        plain_ref = plain(chunks)
+    plain_got, _ = eng.forward_strided(wav.view(-1).to(gpu_device), 16000, 21, 160000)
+    assert north_star_ratio("config1_sample_logp_default_gain", plain_got, plain_ref) <= 1.0
+    # (2) the calibrated (synthetic, high-gain read-out) checkpoint of the pipeline tests: real speech drives
+    #     it so hard that float32 ITSELF is only good to ~1e-2 on its log-probabilities (float32 CPU oracle vs a
+    #     float64 evaluation of the same module), so no float32 implementation can meet 1e-4 against another
+    #     one there.  What is asserted for it is what the pipeline consumes: hard decisions identical wherever
+    #     the oracle's top-2 gap exceeds 1e-4; the errors against float64 are logged.
     with torch.inference_mode():
         ref_logp = seg_o(chunks)
     got_logp = model(chunks.to(gpu_device)).cpu()
-    # Real speech drives this (synthetic, high-gain) read-out far harder than the seeded noise of the
-    # other tests: float32 itself is only good to ~1e-2 on these log-probabilities (the float32 CPU
-    # oracle vs a float64 evaluation of the same module).  The north_star tolerance (rtol 1e-4 / atol
-    # 1e-5 between two float32 implementations) is therefore applied where it is meaningful, and where
-    # it is not the HIP path must be as close to the float64 truth as the float32 oracle is.
     import copy
     with torch.inference_mode():
         ref64 = copy.deepcopy(seg_o).double()(chunks.double())
-    ratio = north_star_ratio("config1_sample_logp", got_logp, ref_logp)
     err_cpu = (ref_logp.double() - ref64).abs().max().item()
     err_gpu = (got_logp.double() - ref64).abs().max().item()
-    with open("gpurun_out/parity.log", "a") as fp:
-        fp.write(f"config1_sample_logp: max|d| vs float64 oracle: float32 oracle {err_cpu:.3e}, "
-                 f"HIP path {err_gpu:.3e}\n")
-    assert ratio <= 1.0 or err_gpu <= 1.25 * err_cpu
     top2 = torch.topk(ref_logp, 2, dim=-1).values
-    safe = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()
+    safe = ((top2[..., 0] - top2[..., 1]) > 1e-4).numpy()
     mism = (swf.data != ref).any(axis=-1)
-    assert not (mism & safe).any()
     with open("gpurun_out/parity.log", "a") as fp:
-        fp.write(f"config1_sample: hard-decision mismatches {int(mism.sum())} of {mism.size} frames "
-                 f"(all inside the 1e-3 top-2 gap)\n")
+        fp.write(f"config1_sample (calibrated read-out): max|d| vs float64: float32 oracle {err_cpu:.3e}, "
+                 f"HIP path {err_gpu:.3e}; hard-decision mismatches {int(mism.sum())} of {mism.size} frames, "
+                 f"{int((mism & safe).sum())} outside the 1e-4 top-2 gap\n")
+    assert not (mism & safe).any()
 
 
 @pytest.mark.gpu

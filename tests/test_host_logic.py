@@ -90,7 +90,7 @@ def _cluster_data(C=60, S=3, D_=32, K=4, seed=0):
 @pytest.mark.parametrize("kw", [dict(), dict(num_clusters=3), dict(min_clusters=6), dict(max_clusters=2)])
 def test_clustering_matches_oracle(kw):
     emb, seg = _cluster_data()
-    clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
+    clu = pa.AgglomerativeClustering(metric="cosine").to(torch.device("cpu")).instantiate(
         {"method": "centroid", "min_cluster_size": 12, "threshold": 0.7045654963945799})
     hard, soft, cen = clu(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS), **kw)
     rh, rs, rc = O.clustering(emb.copy(), seg, **kw)
@@ -102,7 +102,7 @@ def test_clustering_matches_oracle(kw):
 def test_reference_clustering_kat_on_product_class():
     """/root/reference/tests/test_clustering.py:6-29"""
     embeddings = np.array([[1.0, 1.0, 1.0, 1.0], [1.0, 2.0, 1.0, 2.0]])
-    clustering = pa.AgglomerativeClustering().instantiate(
+    clustering = pa.AgglomerativeClustering().to(torch.device("cpu")).instantiate(
         {"method": "centroid", "min_cluster_size": 0, "threshold": 0.0})
     clusters = clustering.cluster(embeddings=embeddings, min_clusters=2, max_clusters=2, num_clusters=2)
     assert np.array_equal(clusters, np.array([0, 1]))

@@ -166,9 +166,13 @@ def test_seg_forward_end_to_end(seg, gpu_device, B, N, stride):
     assert north_star_ratio(f"seg_logp_B{B}_N{N}", logp, ref) <= 1.0
     # hard powerset decisions identical except where the top-2 gap is below tolerance
     top2 = ref.topk(2, dim=-1).values
-    safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-4
     from oracle import Powerset
     ref_ml = Powerset(3, 2)(ref).to(torch.uint8)
+    mism = (ml.cpu() != ref_ml).any(dim=-1)
+    with open("gpurun_out/parity.log", "a") as fp:
+        fp.write(f"seg_hard_B{B}_N{N}: hard-decision mismatches {int(mism.sum())} of {mism.numel()} frames, "
+                 f"{int((mism & safe).sum())} outside the 1e-4 top-2 gap\n")
     assert torch.equal(ml.cpu()[safe], ref_ml[safe])
     # reference Model.forward contract: (B,1,N) in -> (B,F,K) out
     out = eng.forward(chunks[:2].to(gpu_device))
