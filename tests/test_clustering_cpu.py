@@ -122,7 +122,7 @@ def test_unplaced_clustering_object_raises():
     (the SciPy route needs the explicit `.to(torch.device("cpu"))` used throughout this file)."""
     rng = np.random.default_rng(0)
     emb = rng.standard_normal((30, 3, 16)).astype(np.float32)
-    seg = SlidingWindowFeature(np.ones((30, 589, 3), dtype=np.float32), SlidingWindow(0.0, 10.0, 1.0))
+    seg = SlidingWindowFeature(np.ones((30, 589, 3), dtype=np.float32), SlidingWindow(start=0.0, duration=10.0, step=1.0))
     seg.data[:, :, 1:] = 0
     clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
         {"method": "centroid", "min_cluster_size": 2, "threshold": 0.7})
