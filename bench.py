@@ -6,9 +6,11 @@
 One "step" = one pass of the whole pipeline (`Pipeline.__call__` -> sliding-window PyanNet
 segmentation -> speaker counting -> WeSpeaker ResNet34 embeddings -> agglomerative clustering ->
 reconstruction -> Annotation) over one synthetic 1-hour 16 kHz mono recording PER GPU, the waveform
-already resident in HBM when the timed region starts (BASELINE.json configs[3]; N > 1 is configs[4]'s
-"one file per GPU" sharding: every rank diarizes its own file, then ONE RCCL all-gather exchanges the
-per-chunk hard segmentations + embeddings of all files, weak scaling).
+already resident in HBM when the timed region starts (BASELINE.json configs[3]).  N > 1 is configs[4] AS
+WRITTEN: one 1-hour file per GPU and step, ONE RCCL all-gather of the per-chunk hard segmentations +
+embeddings of all files, ONE joint clustering over all of them, reconstruction per file (weak scaling);
+the rate of N independent per-file pipelines (no exchange, per-file clustering) is measured right after
+it and reported under "per_file_clustering" -- it is never `value` at N > 1.
 
 Checkpoints are synthetic (no network): seeded weights in the reference's
 state-dict layout with an extreme-learning-machine read-out so that the segmentation actually tracks
@@ -298,8 +300,10 @@ def main():
                          "seg5s = configs[1] (PyanNet 5 s / 0.5 s over 1 h); emb3s = configs[2] (ResNet34 on "
                          "10 000 x 3 s segments)")
     ap.add_argument("--joint", action="store_true",
-                    help="N > 1: ONE joint clustering over the files of all ranks (configs[4] as written) "
-                         "instead of per-file clustering")
+                    help="(default at N > 1) ONE joint clustering over the files of all ranks = configs[4]; "
+                         "at N = 1 (under torch.distributed.run) the same code path with one rank")
+    ap.add_argument("--per-file", action="store_true",
+                    help="N > 1: headline the per-file-clustering rate (N independent pipelines) instead")
     ap.add_argument("--sequential", action="store_true",
                     help="one pipeline(file) call per step instead of the pipelined apply_batch")
     args = ap.parse_args()
@@ -312,6 +316,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     exchange = dist.is_initialized()
+    joint = exchange and (args.joint or (world > 1 and not args.per_file))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
@@ -334,35 +339,24 @@ def main():
     wav = synth_hour(args.hours, seed=rank, device=device)      # resident in HBM before timing
     file = {"waveform": wav, "sample_rate": 16000, "uri": f"synthetic_{rank}"}
     timer = StageTimer()
-    shard = None
-    if exchange:
-        from pyannote_audio_amd import parallel
-        shard = parallel.shard_from_env()
 
-    def exchange_records():
-        # exchange step of configs[4]: per-chunk hard segmentations + embeddings of every rank's file,
-        # device buffers over RCCL (the joint mode does this inside apply_batch instead)
-        payload = pipeline.last_exchange_payload(device)
-        parallel.all_gather_records(payload, shard)
-
-    def run(num_files: int, tag: str):
-        """`num_files` steps = `num_files` one-hour files through the pipeline.  Default: apply_batch,
-        which overlaps clustering + reconstruction of file i with the front end of file i+1."""
+    def run(num_files: int, tag: str, joint_mode: bool):
+        """`num_files` steps = `num_files` one-hour files through the pipeline.  Per-file clustering:
+        apply_batch, which overlaps clustering + reconstruction of file i with the front end of file i+1.
+        Joint: one apply_batch(joint_clustering=True) per step = front end of this rank's file, all-gather
+        of every rank's records over RCCL, one clustering of all of them, back end of this rank's file."""
         files = [dict(file, uri=f"synthetic_{rank}_{tag}{i}") for i in range(num_files)]
         last = None
-        if args.sequential:
+        if joint_mode:
             for f in files:
-                last = pipeline(f)
-                if exchange:
-                    exchange_records()
-        elif exchange and args.joint:
-            for f in files:       # one joint clustering per step over the files of all ranks
                 for _, last in pipeline.apply_batch([f], joint_clustering=True):
                     pass
+        elif args.sequential:
+            for f in files:
+                last = pipeline(f)
         else:
             for _, last in pipeline(files):
-                if exchange:
-                    exchange_records()
+                pass
         return last
 
     def barrier():
@@ -370,16 +364,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup, "w")
-    barrier()
-    t0 = time.perf_counter()
-    out = run(args.steps, "s")
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if exchange:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(joint_mode: bool, tag: str):
+        run(args.warmup, "w" + tag, joint_mode)
+        barrier()
+        t0 = time.perf_counter()
+        result = run(args.steps, "s" + tag, joint_mode)
+        barrier()
+        dt = time.perf_counter() - t0
+        if exchange:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return result, dt
+
+    out, elapsed = timed(joint, "")
+    joint_info = None
+    if joint:
+        joint_info = {"points": int(getattr(pipeline.clustering, "timings", {}).get("num_embeddings", 0)),
+                      "clustering_s": {k: (round(v, 4) if isinstance(v, float) else v)
+                                       for k, v in pipeline.clustering.timings.items()}}
+    other = None
+    if world > 1:            # the other N > 1 mode, measured in the same run (second key, never `value`)
+        _, other_elapsed = timed(not joint, "o")
+        other = {"value": round(args.hours * world * args.steps / other_elapsed, 5),
+                 "ms_per_step": round(1e3 * other_elapsed / args.steps, 2)}
 
     # ---- stage split of ONE sequential (un-pipelined, untimed) pass: host clock + device sync per stage
     artifacts = {}
@@ -430,12 +438,14 @@ def main():
                                    "window, WeSpeaker ResNet34 embeddings, centroid AHC) on "
                                    f"{args.hours:g} h of 16 kHz mono audio per GPU",
                        "chunks_per_file": int((wav.shape[1] - 160000) // 16000 + 1),
-                       "files": world, "parallelism": f"file-per-gpu x{world}"},
+                       "files": world,
+                       "parallelism": f"file-per-gpu x{world}" + (", joint clustering" if joint else "")},
             "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
-            "mode": "sequential pipeline(file) calls" if args.sequential else
-                    ("apply_batch(joint_clustering=True) per step" if (exchange and args.joint) else
+            "mode": ("configs[4]: one file per GPU and step, RCCL all-gather of the records, ONE joint "
+                     "clustering over all files (apply_batch(joint_clustering=True))") if joint else
+                    ("sequential pipeline(file) calls" if args.sequential else
                      "pipeline([files]) = apply_batch: clustering/back end of file i overlap the front end "
-                     "of file i+1"),
+                     "of file i+1" + (" (N independent per-file pipelines, no exchange)" if world > 1 else "")),
             "sequential_stages_ms": {k: round(1e3 * v, 1) for k, v in stage_sum.items()},
             "speakers": len(out.speaker_diarization.labels()),
             "apply_marks_s": {k: round(v, 4) for k, v in getattr(pipeline, "timings", {}).items()},
@@ -444,7 +454,11 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
-        if getattr(pipeline, "batch_timeline", None):   # host-clock stage boundaries of the timed files
+        if joint_info is not None:
+            line["joint_clustering"] = joint_info
+        if other is not None:
+            line["joint_clustering_rate" if not joint else "per_file_clustering"] = other
+        if getattr(pipeline, "batch_timeline", None) and not joint:   # host-clock stage boundaries of the timed files
             line["batch_timeline_s"] = [{k: round(v, 4) for k, v in f.items()} for f in pipeline.batch_timeline]
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             hour = None

@@ -123,7 +123,6 @@ class SpeakerDiarization(Pipeline):
         self._expects_num_speakers = self.clustering.expects_num_clusters
         self.timings: dict = {}
         self.batch_timeline: list = []       # apply_batch: host-clock stage boundaries per file
-        self._last_front: Optional[_FrontEnd] = None
 
     def _clustering_kwargs(self, name: str, metric: str) -> dict:
         kwargs = {"metric": metric}
@@ -243,12 +242,6 @@ class SpeakerDiarization(Pipeline):
         return frame_ops.Reconstructor(dev_seg, segmentations.sliding_window, self._frames,
                                        hard_clusters, count.data).discretize()
 
-    def last_exchange_payload(self, device: torch.device) -> torch.Tensor:
-        """Device-resident record buffer (parallel.pack_records) of the last file's front end: the send
-        buffer of the multi-file all-gather."""
-        front = self._last_front
-        return parallel.pack_records(front.dev_seg, front.dev_emb).to(device)
-
     # ---------------------------------------------------------------------------------- front end
     def _front_end(self, file: dict, hook: Callable) -> _FrontEnd:
         marks = [("start", time.perf_counter())]
@@ -290,7 +283,6 @@ class SpeakerDiarization(Pipeline):
         if self._embedding is None:            # OracleClustering: no embeddings (:631-636)
             active, clean = frame_ops.chunk_stats(dev_seg)
             front.active, front.clean = active.cpu().numpy(), clean.cpu().numpy()
-            self._last_front = front
             return front
 
         if dev_emb is None:
@@ -307,7 +299,6 @@ class SpeakerDiarization(Pipeline):
         front.active, front.clean = active.cpu().numpy(), clean.cpu().numpy()
         marks.append(("embeddings", time.perf_counter()))
         hook("embeddings", front.embeddings)
-        self._last_front = front
         return front
 
     # ----------------------------------------------------------------------------------- back end
