@@ -35,7 +35,7 @@ def test_clustering_on_gpu_matches_host(gpu_device):
     from test_host_logic import _cluster_data, CHUNKS
     emb, seg = _cluster_data(C=400, D_=256, K=5, seed=9)
     params = {"method": "centroid", "min_cluster_size": 12, "threshold": 0.7045654963945799}
-    host = pa.AgglomerativeClustering().instantiate(params)
+    host = pa.AgglomerativeClustering().instantiate(params).to(torch.device("cpu"))   # explicit SciPy route
     dev = pa.AgglomerativeClustering().instantiate(params).to(gpu_device)
     a = host(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS))
     b = dev(embeddings=emb.copy(), segmentations=SlidingWindowFeature(seg, CHUNKS))
