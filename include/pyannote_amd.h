@@ -229,6 +229,20 @@ int pa_cluster_activations(const uint8_t* seg, int C, int F, int S, const int32_
 int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
                      uint8_t* tie, void* stream);
 
+/* Soft-score (non-powerset segmentation) forms of the same stages:
+ * hysteresis thresholding = `binarize` (utils/signal.py:78-140; pipelines/speaker_diarization.py:599-606):
+ * scores (C,F,K) fp32 -> out (C,F,K) uint8; on where score > onset, off where score < offset, unchanged in
+ * between, NaN = 0; initial_state 0 / 1, or -1 for `scores[:, 0] >= (onset + offset) / 2`. */
+int pa_binarize_hysteresis(const float* scores, int C, int F, int K, float onset, float offset,
+                           int initial_state, uint8_t* out, void* stream);
+/* out (C,F,K) fp32 = max_{s: hard[c][s]==k} scores[c][f][s], NaN when chunk c has no speaker in cluster k
+ * (pipelines/speaker_diarization.py:506-522); overlap-add it with pa_aggregate(skip_average = 1). */
+int pa_cluster_max(const float* scores, int C, int F, int S, const int32_t* hard, int K, float* out,
+                   void* stream);
+/* pa_topk_binarize on fp32 activations (>= 0, no NaN) */
+int pa_topk_binarize_f32(const float* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
+                         uint8_t* tie, void* stream);
+
 /* General overlap-add aggregation, replaces Inference.aggregate (core/inference.py:498-620):
  * scores (C,F,K) fp32 (NaN = missing), window (F) fp64 = Hamming or ones, warm (F) fp64 = warm-up
  * window, start_frame (C) non-decreasing -> out (T,K) fp32 = sum / max(weight sum, epsilon) (or the plain sum), `missing` where

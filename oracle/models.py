@@ -185,8 +185,9 @@ class PyanNet(nn.Module):
 
     def __init__(self, num_classes: int = 7, sincnet: Optional[dict] = None,
                  lstm: Optional[dict] = None, linear: Optional[dict] = None,
-                 sample_rate: int = 16000):
+                 sample_rate: int = 16000, powerset: bool = True):
         super().__init__()
+        self.powerset = powerset
         self.hp_sincnet = {"stride": 10, **(sincnet or {})}
         self.hp_lstm = {"hidden_size": 128, "num_layers": 2, "bidirectional": True,
                         "monolithic": True, "dropout": 0.0, **(lstm or {})}
@@ -206,7 +207,9 @@ class PyanNet(nn.Module):
         if self.hp_linear["num_layers"] > 0:
             self.linear = nn.ModuleList([nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
         self.classifier = nn.Linear(dims[-1], num_classes)
-        self.activation = nn.LogSoftmax(dim=-1)
+        # default_activation (core/model.py:271-299): log-softmax for the (mono-label) powerset problem,
+        # sigmoid for multi-label checkpoints (one score per speaker)
+        self.activation = nn.LogSoftmax(dim=-1) if powerset else nn.Sigmoid()
 
     def num_frames(self, num_samples: int) -> int:
         return self.sincnet.num_frames(num_samples)

@@ -69,11 +69,12 @@ def receptive_field(model, sample_rate: int = 16000) -> SW:
 
 def slide(model, waveform: torch.Tensor, sample_rate: int, duration: float, step: float,
           batch_size: int = 32) -> np.ndarray:
-    """Inference.slide with skip_aggregation=True on a powerset model -> (C, F, S) float32 {0,1}."""
+    """Inference.slide with skip_aggregation=True -> (C, F, S) float32: {0,1} hard multilabel for a
+    powerset model (inference.py:130-136, 210-215), the sigmoid scores themselves for a multi-label one."""
     window_size = round(duration * sample_rate)
     step_size = round(step * sample_rate)
     _, num_samples = waveform.shape
-    conversion = Powerset(3, 2)
+    conversion = Powerset(3, 2) if getattr(model, "powerset", True) else (lambda x: x)
     outputs = []
     if num_samples >= window_size:
         chunks = waveform.unfold(1, window_size, step_size).permute(1, 0, 2)
@@ -124,6 +125,28 @@ def aggregate(scores: np.ndarray, chunks: SW, frames: SW, warm_up=(0.0, 0.0), ep
         average = aggregated_output / np.maximum(overlapping_chunk_count, epsilon)
     average[aggregated_mask == 0.0] = missing
     return average, frames
+
+
+def hysteresis(scores: np.ndarray, onset: float = 0.5, offset: Optional[float] = None,
+               initial_state=None) -> np.ndarray:
+    """`binarize` for (C, F, K) scores (utils/signal.py:78-204): per (chunk, class) on where score > onset,
+    off where score < offset, the previous state in between; NaN -> 0; `initial_state` None means
+    scores[:, 0] >= (onset + offset) / 2.  Written as the state machine the reference's index arithmetic
+    (`same_as` / `well_defined_idx`) evaluates."""
+    offset = offset or onset
+    C, F_, K = scores.shape
+    data = np.nan_to_num(np.transpose(scores, (0, 2, 1)).reshape(C * K, F_))
+    if initial_state is None:
+        state = data[:, 0] >= 0.5 * (onset + offset)
+    else:
+        state = np.full(C * K, bool(initial_state))
+    out = np.zeros((C * K, F_), dtype=bool)
+    state = state.copy()
+    for f in range(F_):
+        col = data[:, f]
+        state = np.where(col > onset, True, np.where(col < offset, False, state))
+        out[:, f] = state
+    return 1.0 * np.transpose(out.reshape(C, K, F_), (0, 2, 1))
 
 
 def speaker_count(binarized: np.ndarray, chunks: SW, frames: SW) -> Tuple[np.ndarray, SW]:
@@ -360,13 +383,15 @@ class OracleOutput:
     embeddings: Optional[np.ndarray]
     hard_clusters: Optional[np.ndarray]
     timings: dict
+    raw_segmentations: Optional[np.ndarray] = None     # what Inference.slide returned (soft for non-powerset)
 
 
 def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 16000,
             duration: float = 10.0, segmentation_step: float = 0.1, exclude_overlap: bool = True,
             segmentation_batch_size: int = 32, embedding_batch_size: int = 32,
             num_speakers=None, min_speakers=None, max_speakers=None,
-            method="centroid", threshold=0.7045654963945799, min_cluster_size=12) -> OracleOutput:
+            method="centroid", threshold=0.7045654963945799, min_cluster_size=12,
+            segmentation_threshold: float = 0.5) -> OracleOutput:
     """SpeakerDiarization.apply (speaker_diarization.py:530-784) for the 3.1 configuration."""
     import time
     timings = {}
@@ -378,7 +403,10 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
     frames = receptive_field(seg_model, sample_rate)
 
     t0 = time.perf_counter()
-    segmentations = slide(seg_model, waveform, sample_rate, duration, chunks.step, segmentation_batch_size)
+    raw = slide(seg_model, waveform, sample_rate, duration, chunks.step, segmentation_batch_size)
+    # non-powerset models: hysteresis thresholding (:599-606); the RAW scores are reconstructed from (:687)
+    segmentations = raw if getattr(seg_model, "powerset", True) else \
+        hysteresis(raw, onset=segmentation_threshold, initial_state=False).astype(np.float32)
     timings["segmentation"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     count, count_frames = speaker_count(segmentations, chunks, frames)
@@ -399,10 +427,10 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
     count = np.minimum(count, max_speakers_).astype(np.int8)
     inactive_speakers = np.sum(segmentations, axis=1) == 0
     hard_clusters[inactive_speakers] = -2
-    discrete = reconstruct(segmentations, chunks, hard_clusters, count, count_frames)
+    discrete = reconstruct(raw, chunks, hard_clusters, count, count_frames)
     tracks = binarize(discrete, count_frames)
     count1 = np.minimum(count, 1).astype(np.int8)
-    exclusive = reconstruct(segmentations, chunks, hard_clusters, count1, count_frames)
+    exclusive = reconstruct(raw, chunks, hard_clusters, count1, count_frames)
     ex_tracks = binarize(exclusive, count_frames)
     labels = sorted({tr[3] for tr in tracks}, key=str)
     mapping = {label: f"SPEAKER_{i:02d}" for i, label in enumerate(labels)}
@@ -414,4 +442,4 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
     new_labels = sorted(mapping.values(), key=str)
     centroids = centroids[[inverse_mapping[label] for label in new_labels]]
     timings["reconstruction"] = time.perf_counter() - t0
-    return OracleOutput(diar, exdiar, centroids, segmentations, count, embeddings, hard_clusters, timings)
+    return OracleOutput(diar, exdiar, centroids, segmentations, count, embeddings, hard_clusters, timings, raw)

@@ -113,6 +113,40 @@ def models_from_readout(classifier_weight, classifier_bias, seg1_bias, seg_seed:
     return seg, emb
 
 
+def calibrated_multilabel_pyannet(seed: int = 1234, num_layers: int = 4, calib_seconds: float = 60.0,
+                                  chunk_s: float = 10.0, ridge: float = 1e-2, gain: float = 8.0) -> PyanNet:
+    """NON-powerset variant (multi-label problem: one sigmoid score per local speaker, core/model.py:
+    286-294): same seeded trunk, a ridge read-out fitted to the three per-speaker activities."""
+    base = uncalibrated_pyannet(seed=seed, num_layers=num_layers)
+    model = PyanNet(num_classes=3, lstm={"num_layers": num_layers}, powerset=False)
+    sd = {k: v for k, v in base.state_dict().items() if not k.startswith("classifier.")}
+    model.load_state_dict(sd, strict=False)
+    model.eval()
+    wav, act = synth_conversation(calib_seconds, seed=seed + 1)
+    N = int(chunk_s * 16000)
+    feats, targets = [], []
+    hooked = {}
+    handle = model.classifier.register_forward_hook(lambda m, i, o: hooked.__setitem__("x", i[0]))
+    with torch.inference_mode():
+        for s in range(0, wav.shape[1] - N + 1, N // 2):
+            model(wav[:, s:s + N][None])
+            x = hooked["x"][0].numpy()
+            feats.append(x)
+            cls = _frame_targets(act[:, s:s + N], x.shape[0])
+            targets.append(np.array([[1.0 if k in _POWERSET[c] else 0.0 for k in range(3)] for c in cls]))
+    handle.remove()
+    X = np.concatenate(feats).astype(np.float64)
+    Y = np.concatenate(targets)
+    mu, ym = X.mean(0), Y.mean(0)
+    Xc = X - mu
+    W = np.linalg.solve(Xc.T @ Xc + ridge * len(X) * np.eye(X.shape[1]), Xc.T @ (Y - ym))   # (128, 3)
+    b = ym - mu @ W
+    with torch.no_grad():     # sigmoid(gain * (regression - 1/2)): > 0.5 where the regression says "active"
+        model.classifier.weight.copy_(torch.from_numpy((gain * W.T).astype(np.float32)))
+        model.classifier.bias.copy_(torch.from_numpy((gain * (b - 0.5)).astype(np.float32)))
+    return model
+
+
 def calibrated_pyannet(seed: int = 1234, num_layers: int = 4, calib_seconds: float = 120.0,
                        chunk_s: float = 10.0, ridge: float = 1e-2, gain: float = 6.0) -> PyanNet:
     """seeded PyanNet whose classifier is a ridge read-out fitted on a synthetic conversation."""

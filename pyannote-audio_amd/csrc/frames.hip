@@ -135,23 +135,39 @@ __global__ __launch_bounds__(256) void k_cluster_scatter(const uint8_t* __restri
 }
 
 // out[t][k] = 1 for the min(count[t], cap, K) largest act[t][.], ties -> lowest k.  One thread per frame.
-__global__ __launch_bounds__(256) void k_topk_binarize(const int* __restrict__ act,
+// VT = int (hard {0,1} segmentations: sums of small integers) or float (soft scores of non-powerset models:
+// activations are >= 0 sums of sigmoid scores, never NaN after aggregate(missing=0)).
+template <typename VT>
+struct TopkTop;
+template <>
+struct TopkTop<int> {
+  static __device__ __forceinline__ int value() { return 0x7fffffff; }
+};
+template <>
+struct TopkTop<float> {
+  static __device__ __forceinline__ float value() { return __builtin_inff(); }
+};
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_topk_binarize(const VT* __restrict__ act,
                                                         const uint8_t* __restrict__ count, int T, int K,
                                                         int cap, uint8_t* __restrict__ out,
                                                         uint8_t* __restrict__ tie) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
-  const int* a = act + (long)t * K;
+  const VT* a = act + (long)t * K;
   uint8_t* o = out + (long)t * K;
   for (int k = 0; k < K; ++k) o[k] = 0;
   int n = count[t];
   n = n < cap ? n : cap;
   n = n < K ? n : K;
-  int last_v = 0x7fffffff, last_k = -1;  // previously selected (value, index): next pick is "after" it
+  VT last_v = TopkTop<VT>::value();
+  int last_k = -1;  // previously selected (value, index): next pick is "after" it
   for (int i = 0; i < n; ++i) {
-    int best_v = -1, best_k = -1;
+    VT best_v = (VT)-1;
+    int best_k = -1;
     for (int k = 0; k < K; ++k) {
-      const int v = a[k];
+      const VT v = a[k];
       const bool after = v < last_v || (v == last_v && k > last_k);
       if (after && v > best_v) {
         best_v = v;
@@ -170,9 +186,92 @@ __global__ __launch_bounds__(256) void k_topk_binarize(const int* __restrict__ a
   tie[t] = amb ? 1 : 0;
 }
 
+// Hysteresis thresholding, replaces `binarize` (utils/signal.py:78-140) for non-powerset segmentation
+// models (pipelines/speaker_diarization.py:599-606): per (chunk, class) a state machine over the frames --
+// on where score > onset, off where score < offset, unchanged in between; NaN counts as 0 (nan_to_num).
+// initial: 0 / 1 = given state, -1 = `scores[0] >= (onset + offset) / 2`.  One thread per (chunk, class).
+__global__ __launch_bounds__(256) void k_hysteresis(const float* __restrict__ scores, long rows, int F, int K,
+                                                     float onset, float offset, int initial,
+                                                     uint8_t* __restrict__ out) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;  // r = c * K + k
+  if (r >= rows) return;
+  const long c = r / K;
+  const int k = (int)(r % K);
+  const float* p = scores + c * F * K + k;
+  uint8_t* q = out + c * F * K + k;
+  float s0 = p[0];
+  s0 = s0 != s0 ? 0.f : s0;
+  bool state = initial < 0 ? (s0 >= 0.5f * (onset + offset)) : (initial != 0);
+  for (int f = 0; f < F; ++f) {
+    float s = p[(long)f * K];
+    s = s != s ? 0.f : s;
+    if (s > onset) state = true;
+    else if (s < offset) state = false;
+    q[(long)f * K] = state ? 1 : 0;
+  }
+}
+
+// clustered[c][f][k] = max over the local speakers s with hard[c][s] == k of scores[c][f][s], NaN when the
+// chunk has none (pipelines/speaker_diarization.py:506-522) -- the soft-score form of k_cluster_scatter's
+// first half; the overlap-add SUM is pa_aggregate(skip_average) on the result.
+__global__ __launch_bounds__(256) void k_cluster_max(const float* __restrict__ scores, long CF, int F, int S,
+                                                      const int* __restrict__ hard, int K,
+                                                      float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (c, f)
+  if (i >= CF) return;
+  const long c = i / F;
+  const float* p = scores + i * S;
+  for (int k = 0; k < K; ++k) {
+    float best = __builtin_nanf("");
+    bool any = false;
+    for (int s = 0; s < S; ++s)
+      if (hard[c * S + s] == k) {
+        const float v = p[s];
+        // np.max propagates NaN; otherwise the larger value
+        if (!any) best = v;
+        else if (v != v || best != best) best = __builtin_nanf("");
+        else best = v > best ? v : best;
+        any = true;
+      }
+    out[i * K + k] = best;
+  }
+}
+
 }  // namespace pa
 
 extern "C" {
+
+int pa_binarize_hysteresis(const float* scores, int C, int F, int K, float onset, float offset,
+                           int initial_state, uint8_t* out, void* stream) {
+  if (C <= 0 || F <= 0 || K <= 0) return 0;
+  const long rows = (long)C * K;
+  pa::ProfScope prof("k_hysteresis", stream, 2.0 * rows * F, 5.0 * rows * F);
+  hipLaunchKernelGGL(pa::k_hysteresis, dim3(pa::cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, scores,
+                     rows, F, K, onset, offset, initial_state, out);
+  PA_CHECK_LAUNCH("pa_binarize_hysteresis");
+  return 0;
+}
+
+int pa_cluster_max(const float* scores, int C, int F, int S, const int32_t* hard, int K, float* out,
+                   void* stream) {
+  if (C <= 0 || F <= 0 || K <= 0) return 0;
+  const long CF = (long)C * F;
+  pa::ProfScope prof("k_cluster_max", stream, 1.0 * CF * S * K, 4.0 * CF * (S + K));
+  hipLaunchKernelGGL(pa::k_cluster_max, dim3(pa::cdiv(CF, 256)), dim3(256), 0, (hipStream_t)stream, scores, CF,
+                     F, S, hard, K, out);
+  PA_CHECK_LAUNCH("pa_cluster_max");
+  return 0;
+}
+
+int pa_topk_binarize_f32(const float* act, const uint8_t* count, int T, int K, int cap, uint8_t* out,
+                         uint8_t* tie, void* stream) {
+  if (T <= 0 || K <= 0) return 0;
+  pa::ProfScope prof("k_topk_binarize", stream, 1.0 * T * K, 5.0 * T * K + T);
+  hipLaunchKernelGGL(pa::k_topk_binarize<float>, dim3(pa::cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream,
+                     act, count, T, K, cap, out, tie);
+  PA_CHECK_LAUNCH("pa_topk_binarize_f32");
+  return 0;
+}
 
 int pa_seg_chunk_stats(const uint8_t* seg, int C, int F, int S, int32_t* active, int32_t* clean,
                        void* stream) {
@@ -232,7 +331,7 @@ int pa_topk_binarize(const int32_t* act, const uint8_t* count, int T, int K, int
                      uint8_t* tie, void* stream) {
   if (T <= 0 || K <= 0) return 0;
   pa::ProfScope prof("k_topk_binarize", stream, 1.0 * T * K, 5.0 * T * K + T);
-  hipLaunchKernelGGL(pa::k_topk_binarize, dim3(pa::cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, act,
+  hipLaunchKernelGGL(pa::k_topk_binarize<int>, dim3(pa::cdiv(T, 256)), dim3(256), 0, (hipStream_t)stream, act,
                      count, T, K, cap, out, tie);
   PA_CHECK_LAUNCH("pa_topk_binarize");
   return 0;

@@ -8,7 +8,8 @@
 //                 256 KB) lives in the register file of the CU for the whole sequence: 4 waves x 256
 //                 VGPRs as MFMA B operands; h_t goes through a double-buffered 16x128 LDS tile; the
 //                 cell state never leaves registers.  589 dependent steps, one barrier per step.
-//   k_classifier  Linear(K -> NC) + log-softmax + powerset arg-max -> multilabel LUT.
+//   k_classifier  Linear(K -> NC) + log-softmax + powerset arg-max -> multilabel LUT; or, for multi-label
+//                 (non-powerset) checkpoints, Linear(K -> NC) + sigmoid (core/model.py:271-299).
 //
 // Row order of all [m][*] activations in the LSTM stack: m = (tile*T + t)*16 + b16 (b = 16*tile+b16),
 // i.e. the 16 chunks of a tile are adjacent for a fixed time step, which is exactly the MFMA M
@@ -276,6 +277,14 @@ __global__ __launch_bounds__(256) void k_classifier(const float* __restrict__ X,
         z[cidx] = fmaf(xv.w, wrow[3], z[cidx]);
       }
   }
+  const long o = (long)b * T + t;
+  if (mapping == nullptr) {
+    // multi-label / binary problems: sigmoid scores (default_activation, core/model.py:286-294); the hard
+    // decisions come from the hysteresis kernel (frames.hip: k_hysteresis), not from here
+    if (logp != nullptr)
+      for (int cidx = 0; cidx < NC; ++cidx) logp[o * NC + cidx] = 1.f / (1.f + expf(-z[cidx]));
+    return;
+  }
   float mx = z[0];
   int am = 0;
 #pragma unroll
@@ -289,7 +298,6 @@ __global__ __launch_bounds__(256) void k_classifier(const float* __restrict__ X,
   for (int cidx = 0; cidx < CLS_MAXC; ++cidx)
     if (cidx < NC) se += expf(z[cidx] - mx);
   const float lse = mx + logf(se);
-  const long o = (long)b * T + t;
   if (logp != nullptr)
     for (int cidx = 0; cidx < NC; ++cidx) logp[o * NC + cidx] = z[cidx] - lse;
   if (ml != nullptr)

@@ -130,6 +130,10 @@ _OPTIONAL: list[tuple] = [
     ("pa_cluster_activations", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp],
      C.c_int),
     ("pa_topk_binarize", [c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_topk_binarize_f32", [c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_binarize_hysteresis", [c_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, c_fp, c_fp],
+     C.c_int),
+    ("pa_cluster_max", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_aggregate", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, C.c_float, C.c_float, C.c_int,
                       c_fp, c_fp], C.c_int),
     ("pa_resample_poly", [c_fp, C.c_long, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_long, c_fp],

@@ -98,6 +98,22 @@ def aggregate(scores, chunks: SlidingWindow, frames: SlidingWindow, device: torc
     return SlidingWindowFeature(out.cpu().numpy(), out_frames)
 
 
+@ffi.on_device(lambda scores, *a, **k: scores.device)
+def binarize(scores: torch.Tensor, onset: float = 0.5, offset: float | None = None,
+             initial_state: bool | None = None) -> torch.Tensor:
+    """`binarize` (utils/signal.py:78-204) on the device: (C, F, K) float32 scores -> (C, F, K) uint8 by
+    hysteresis thresholding per (chunk, class); what SpeakerDiarization.apply does to the segmentations of a
+    non-powerset model (pipelines/speaker_diarization.py:599-606)."""
+    offset = offset or onset
+    x = scores.to(torch.float32).contiguous()
+    C, F, K = x.shape
+    out = torch.empty((C, F, K), dtype=torch.uint8, device=x.device)
+    init = -1 if initial_state is None else int(bool(initial_state))
+    ffi.check(ffi.load().pa_binarize_hysteresis(ffi.ptr(x), C, F, K, float(onset), float(offset), init,
+                                                ffi.ptr(out), ffi.stream()), "pa_binarize_hysteresis")
+    return out
+
+
 class Reconstructor:
     """speaker_diarization.py:480-528 + diarization.py:221-268: cluster activations are accumulated
     once, then discretised for any per-frame cap (regular and exclusive diarization share them)."""
@@ -105,7 +121,11 @@ class Reconstructor:
     @ffi.on_device(lambda self, seg, *a, **k: seg.device)
     def __init__(self, seg: torch.Tensor, chunks: SlidingWindow, frames: SlidingWindow,
                  hard_clusters: np.ndarray, count: np.ndarray):
+        """`seg`: (C, F, S) uint8 hard segmentations (powerset models: sums of small integers), or float32
+        soft scores (non-powerset models: the reference reconstructs from the RAW segmentations,
+        speaker_diarization.py:687-691, so activations are float32 overlap-add sums of sigmoid scores)."""
         C, F, S = seg.shape
+        self.soft = seg.dtype != torch.uint8
         dev = seg.device
         starts, T, self.frames = frame_geometry(chunks, frames, C)
         count = np.ascontiguousarray(count.reshape(-1))
@@ -118,6 +138,18 @@ class Reconstructor:
         self.count = torch.from_numpy(count.astype(np.uint8)).to(dev)
         hard = torch.from_numpy(np.ascontiguousarray(hard_clusters, dtype=np.int32)).to(dev)
         st = torch.from_numpy(starts).to(dev)
+        if self.soft:
+            lib = ffi.load()
+            clustered = torch.empty((C, F, self.K), dtype=torch.float32, device=dev)
+            ffi.check(lib.pa_cluster_max(ffi.ptr(seg.contiguous()), C, F, S, ffi.ptr(hard), self.K,
+                                         ffi.ptr(clustered), ffi.stream()), "pa_cluster_max")
+            ones = torch.ones(F, dtype=torch.float64, device=dev)
+            self.act = torch.empty((T, self.K), dtype=torch.float32, device=dev)
+            # aggregate(hamming=False, missing=0, skip_average=True) (diarization.py:243-249)
+            ffi.check(lib.pa_aggregate(ffi.ptr(clustered), C, F, self.K, ffi.ptr(st), T, ffi.ptr(ones),
+                                       ffi.ptr(ones), 1e-12, 0.0, 1, ffi.ptr(self.act), ffi.stream()),
+                      "pa_aggregate")
+            return
         self.act = torch.empty((T, self.K), dtype=torch.int32, device=dev)
         ffi.check(ffi.load().pa_cluster_activations(ffi.ptr(seg), C, F, S, ffi.ptr(st), ffi.ptr(hard),
                                                     self.K, T, ffi.ptr(self.act), ffi.stream()),
@@ -133,9 +165,9 @@ class Reconstructor:
         dev = self.act.device
         out = torch.empty((self.T, self.K), dtype=torch.uint8, device=dev)
         tie = torch.empty(self.T, dtype=torch.uint8, device=dev)
-        ffi.check(ffi.load().pa_topk_binarize(ffi.ptr(self.act), ffi.ptr(self.count), self.T, self.K,
-                                              int(cap), ffi.ptr(out), ffi.ptr(tie), ffi.stream()),
-                  "pa_topk_binarize")
+        topk = ffi.load().pa_topk_binarize_f32 if self.soft else ffi.load().pa_topk_binarize
+        ffi.check(topk(ffi.ptr(self.act), ffi.ptr(self.count), self.T, self.K, int(cap), ffi.ptr(out),
+                       ffi.ptr(tie), ffi.stream()), "pa_topk_binarize")
         idx = torch.nonzero(tie).view(-1)
         binary = out.cpu().numpy().astype(np.float32)
         if idx.numel():

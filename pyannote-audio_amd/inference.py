@@ -119,9 +119,9 @@ class Inference(BaseInference):
         """waveform: (1, num_samples), host or device.  `chunk_range` restricts processing to chunks
         [begin, end) (multi-GPU sharding); geometry is always that of the whole file."""
         specifications = self.model.specifications
-        if specifications.resolution != Resolution.FRAME or not specifications.powerset:
-            raise NotImplementedError("the accelerated sliding window covers frame-level powerset "
-                                      "segmentation models (the 3.1 hot path)")
+        if specifications.resolution != Resolution.FRAME:
+            raise NotImplementedError("the accelerated sliding window covers frame-level segmentation "
+                                      "models (powerset, as on the 3.1 hot path, or multi-label)")
         window_size: int = self.model.audio.get_num_samples(self.duration)
         step_size: int = round(self.step * sample_rate)
         _, num_samples = waveform.shape
@@ -132,11 +132,13 @@ class Inference(BaseInference):
         wav = waveform.to(self.model.device, torch.float32).contiguous().view(-1)
         if hook is not None:
             hook(completed=0, total=total)
-        want_logp = self.skip_conversion
+        # multi-label checkpoints have no powerset conversion: their sigmoid scores are the output and the
+        # pipeline binarizes them itself (pipelines/speaker_diarization.py:599-606)
+        want_logp = self.skip_conversion or not specifications.powerset
         sub = wav[begin * step_size:]
         logp, ml = self._forward(sub, step_size, end - begin, window_size,
                                  want_logp=want_logp, want_multilabel=not want_logp)
-        self.last_device_output = ml
+        self.last_device_output = ml if ml is not None else logp
         self.last_enqueued = time.perf_counter()     # host clock when the launch group was queued
         outputs = (logp if want_logp else ml.to(torch.float32)).cpu().numpy()
         self.last_host_output = None if want_logp else outputs

@@ -346,14 +346,21 @@ class PyanNet(Model):
         from .segmentation import SegmentationEngine
         from .weights import SegmentationPack
         s = self.specifications
-        if not s.powerset:
-            raise NotImplementedError("only powerset segmentation models are on the accelerated path")
-        pack = SegmentationPack(self._state_dict, dict(self.hparams), s.num_powerset_classes,
-                                len(s.classes), s.powerset_max_classes, device)
+        if s.powerset:
+            pack = SegmentationPack(self._state_dict, dict(self.hparams), s.num_powerset_classes,
+                                    len(s.classes), s.powerset_max_classes, device)
+        elif s.problem in (Problem.MULTI_LABEL_CLASSIFICATION, Problem.BINARY_CLASSIFICATION):
+            # sigmoid scores per class (default_activation, core/model.py:286-294)
+            pack = SegmentationPack(self._state_dict, dict(self.hparams), len(s.classes), len(s.classes),
+                                    None, device)
+        else:
+            raise NotImplementedError(f"{s.problem} heads are outside the accelerated path (powerset or "
+                                      "multi-label frame-level segmentation)")
         return SegmentationEngine(pack)
 
     def __call__(self, waveforms: torch.Tensor) -> torch.Tensor:
-        """(batch, 1, samples) -> (batch, frames, classes) log-probabilities (PyanNet.py:211-240)."""
+        """(batch, 1, samples) -> (batch, frames, classes) log-probabilities, or sigmoid scores for a
+        multi-label checkpoint (PyanNet.py:211-240)."""
         return self.engine.forward(waveforms)
 
     forward = __call__
@@ -440,8 +447,13 @@ class WeSpeakerResNet293(WeSpeakerResNet34):
 # ---------------------------------------------------------------------------------------------
 # synthetic checkpoints in the reference layout (no pretrained weights are available offline)
 # ---------------------------------------------------------------------------------------------
-def segmentation_specifications(duration: float = 10.0) -> Specifications:
-    """segmentation-3.0: powerset of 3 speakers, at most 2 simultaneously."""
+def segmentation_specifications(duration: float = 10.0, powerset: bool = True) -> Specifications:
+    """segmentation-3.0: powerset of 3 speakers, at most 2 simultaneously (SURVEY.md section 2);
+    `powerset=False`: the pre-3.0 multi-label form (one sigmoid score per speaker)."""
+    if not powerset:
+        return Specifications(problem=Problem.MULTI_LABEL_CLASSIFICATION, resolution=Resolution.FRAME,
+                              duration=duration, min_duration=None, warm_up=(0.0, 0.0),
+                              classes=["speaker#1", "speaker#2", "speaker#3"], permutation_invariant=True)
     return Specifications(problem=Problem.MONO_LABEL_CLASSIFICATION, resolution=Resolution.FRAME,
                           duration=duration, min_duration=None, warm_up=(0.0, 0.0),
                           classes=["speaker#1", "speaker#2", "speaker#3"], powerset_max_classes=2,

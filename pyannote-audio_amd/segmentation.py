@@ -42,7 +42,9 @@ class SegmentationEngine:
     def forward_strided(self, wav: torch.Tensor, chunk_stride: int, num_chunks: int, num_samples: int,
                         want_logp: bool = True, want_multilabel: bool = True):
         """wav: 1-D fp32 device tensor; chunk c = wav[c*stride : c*stride + num_samples] (zero padded
-        past the end).  Returns (logp (C,F,K) fp32 | None, multilabel (C,F,S) uint8 | None)."""
+        past the end).  Returns (logp (C,F,K) fp32 | None, multilabel (C,F,S) uint8 | None); for a
+        multi-label (non-powerset) checkpoint the first item holds the sigmoid SCORES and there is no hard
+        output here (hysteresis thresholding is a pipeline stage: frames.binarize)."""
         lib = ffi.load()
         w = self.pack.struct
         assert wav.dim() == 1 and wav.dtype == torch.float32
@@ -50,6 +52,8 @@ class SegmentationEngine:
         if F <= 0:
             raise ValueError(f"chunks of {num_samples} samples are too short for SincNet")
         dev = self.pack.device
+        if not self.pack.powerset:
+            want_logp, want_multilabel = True, False
         logp = torch.empty((num_chunks, F, w.num_classes), dtype=torch.float32, device=dev) \
             if want_logp else None
         ml = torch.empty((num_chunks, F, w.num_speakers), dtype=torch.uint8, device=dev) \

@@ -64,18 +64,16 @@ class _FrontEnd:
     file: dict
     chunks: SlidingWindow                          # chunk grid of the WHOLE file
     segmentations: SlidingWindowFeature            # host, float32 {0,1}, (C, F, S)
-    dev_seg: torch.Tensor                          # device, uint8, (C, F, S)
+    dev_seg: torch.Tensor                          # device, uint8, (C, F, S): hard (binarized) decisions
     count: SlidingWindowFeature                    # host, uint8, (T, 1)
+    dev_scores: Optional[torch.Tensor] = None      # device, float32 (C, F, S): soft scores (non-powerset)
+    silent: bool = False                           # nobody speaks anywhere in the file
     active: Optional[np.ndarray] = None            # (C, S) frames a local speaker is on
     clean: Optional[np.ndarray] = None             # (C, S) frames it speaks alone
     embeddings: Optional[np.ndarray] = None        # host, float32, (C, S, D)
     dev_emb: Optional[torch.Tensor] = None
     marks: list = field(default_factory=list)
     enqueued: dict = field(default_factory=dict)   # host clock when a stage's launches were all queued
-
-    @property
-    def silent(self) -> bool:
-        return self.embeddings is None
 
 
 class SpeakerDiarization(Pipeline):
@@ -258,6 +256,14 @@ class SpeakerDiarization(Pipeline):
 
         segmentations = self.get_segmentations(file, hook=hook, waveform=waveform, chunk_range=chunk_range)
         dev_seg = self._segmentation.last_device_output
+        dev_scores = None
+        if not self._segmentation.model.specifications.powerset:
+            # non-powerset model: hysteresis thresholding of the sigmoid scores (:599-606, utils/signal.py:
+            # 78-204) -- counting, masks and clustering use the binary form, reconstruction the raw scores
+            if shard.world_size > 1:
+                raise NotImplementedError("chunk sharding exchanges hard (powerset) segmentations only")
+            dev_scores = dev_seg
+            dev_seg = frame_ops.binarize(dev_scores, onset=self.segmentation.threshold, initial_state=False)
         marks.append(("segmentation", time.perf_counter()))
         enqueued = {"segmentation": self._segmentation.last_enqueued}
 
@@ -277,8 +283,11 @@ class SpeakerDiarization(Pipeline):
         marks.append(("speaker_counting", time.perf_counter()))
         hook("speaker_counting", count)
         front = _FrontEnd(file=file, chunks=chunks, segmentations=segmentations, dev_seg=dev_seg,
-                          count=count, marks=marks, enqueued=enqueued)
+                          count=count, marks=marks, enqueued=enqueued, dev_scores=dev_scores)
+        if dev_scores is not None:             # the clustering filters on the BINARIZED segmentations (:642)
+            front.segmentations = SlidingWindowFeature(dev_seg.cpu().numpy().astype(np.float32), chunks)
         if np.nanmax(count.data) == 0.0:
+            front.silent = True
             return front                       # nobody speaks: no embeddings (:617-629)
         if self._embedding is None:            # OracleClustering: no embeddings (:631-636)
             active, clean = frame_ops.chunk_stats(dev_seg)
@@ -332,7 +341,8 @@ class SpeakerDiarization(Pipeline):
         # a local speaker that never speaks belongs to no cluster (:681-685)
         hard_clusters = np.where(front.active == 0, -2, hard_clusters)
         capped = np.minimum(front.count.data, max_speakers).astype(np.int8)          # (:676)
-        rec = frame_ops.Reconstructor(front.dev_seg, front.chunks, self._frames, hard_clusters, capped)
+        rec = frame_ops.Reconstructor(front.dev_seg if front.dev_scores is None else front.dev_scores,
+                                      front.chunks, self._frames, hard_clusters, capped)   # (:687-691)
         regular = rec.discretize()
         marks.append(("reconstruction", time.perf_counter()))
         hook("discrete_diarization", regular)
@@ -542,7 +552,8 @@ class SpeakerDiarization(Pipeline):
         """joint labels: SPEAKER_k = global cluster k in every file (no per-file renumbering)."""
         hard = np.where(front.active == 0, -2, hard)
         capped = np.minimum(front.count.data, max_speakers).astype(np.int8)
-        rec = frame_ops.Reconstructor(front.dev_seg, front.chunks, self._frames, hard, capped)
+        rec = frame_ops.Reconstructor(front.dev_seg if front.dev_scores is None else front.dev_scores,
+                                      front.chunks, self._frames, hard, capped)
         regular = rec.discretize()
         hook("discrete_diarization", regular)
         exclusive = rec.discretize(cap=1)

@@ -157,9 +157,16 @@ class SegmentationPack:
             w.lin_b[l] = self._up(sd[f"linear.{l}.bias"]).value
         w.cls_w = self._up(sd["classifier.weight"])
         w.cls_b = self._up(sd["classifier.bias"])
-        self.mapping = powerset_mapping(num_speakers, max_set_size)
-        assert self.mapping.shape[0] == num_classes
-        w.powerset_map = self._up(self.mapping)
+        # max_set_size None / 0 = a multi-label (non-powerset) checkpoint: sigmoid scores, no look-up table
+        self.powerset = bool(max_set_size)
+        if self.powerset:
+            self.mapping = powerset_mapping(num_speakers, max_set_size)
+            assert self.mapping.shape[0] == num_classes
+            w.powerset_map = self._up(self.mapping)
+        else:
+            assert num_classes == num_speakers
+            self.mapping = None
+            w.powerset_map = None
         self.struct = w
 
     def _up(self, t: torch.Tensor):

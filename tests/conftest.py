@@ -65,7 +65,7 @@ WESPEAKER_HPARAMS = {"sample_rate": 16000, "num_channels": 1, "num_mel_bins": 80
                      "frame_shift": 10, "dither": 0.0, "window_type": "hamming", "use_energy": False}
 
 
-def write_pipeline_dir(root, seg_model, emb_model, config_extra=None):
+def write_pipeline_dir(root, seg_model, emb_model, config_extra=None, powerset=True):
     """synthetic `speaker-diarization-3.1`-style directory: config.yaml + two reference-format
     checkpoints under $model/segmentation and $model/embedding."""
     import yaml
@@ -75,7 +75,7 @@ def write_pipeline_dir(root, seg_model, emb_model, config_extra=None):
     os.makedirs(os.path.join(root, "segmentation"), exist_ok=True)
     os.makedirs(os.path.join(root, "embedding"), exist_ok=True)
     save_checkpoint(os.path.join(root, "segmentation", "pytorch_model.bin"), seg_model.state_dict(),
-                    PYANNET_HPARAMS, PyanNet.ARCHITECTURE, segmentation_specifications(10.0))
+                    PYANNET_HPARAMS, PyanNet.ARCHITECTURE, segmentation_specifications(10.0, powerset))
     save_checkpoint(os.path.join(root, "embedding", "pytorch_model.bin"), emb_model.state_dict(),
                     WESPEAKER_HPARAMS, WeSpeakerResNet34.ARCHITECTURE, embedding_specifications())
     config = {
@@ -87,7 +87,8 @@ def write_pipeline_dir(root, seg_model, emb_model, config_extra=None):
                                 "segmentation": "$model/segmentation", "segmentation_batch_size": 32}},
         "params": {"clustering": {"method": "centroid", "min_cluster_size": 12,
                                   "threshold": 0.7045654963945799},
-                   "segmentation": {"min_duration_off": 0.0}},
+                   "segmentation": {"min_duration_off": 0.0} if powerset else
+                   {"threshold": 0.5, "min_duration_off": 0.0}},
     }
     if config_extra:
         config.update(config_extra)   # (whole top-level sections are replaced)

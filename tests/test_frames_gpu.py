@@ -2,6 +2,10 @@
 speaker_count / reconstruct / to_diarization / filter statistics: bit-exact (integer work)."""
 import numpy as np
 import pytest
+import torch
+
+from pyannote_audio_amd import frames as frame_ops
+from pyannote_audio_amd.core import SlidingWindow
 
 pytestmark = pytest.mark.gpu
 
@@ -75,3 +79,44 @@ def test_chunk_stats_and_masks(gpu_device):
                 use_clean = exclude and clean_seg[c, :, s].sum() > min_num_frames
                 want[c, s] = clean_seg[c, :, s] if use_clean else seg[c, :, s]
         assert np.array_equal(masks, want)
+
+
+# ---------------------------------------------------------------------------- a14: non-powerset (soft) path
+def test_hysteresis_kernel_matches_oracle(gpu_device):
+    """pa_binarize_hysteresis vs oracle.pipeline.hysteresis (= the reference's `binarize`, pinned by
+    tests/test_reference_pipeline.py): NaN scores, scores exactly on a threshold, all initial states."""
+    from oracle import pipeline as op
+    rng = np.random.default_rng(6)
+    scores = rng.uniform(size=(37, 589, 3)).astype(np.float32)
+    scores[2, 10:14, 1] = np.nan
+    scores[3, ::9, 0] = 0.6
+    scores[4, ::7, 2] = 0.4
+    dev = torch.from_numpy(scores).to(gpu_device)
+    for onset, offset, init in [(0.5, None, False), (0.6, 0.4, None), (0.6, 0.4, True), (0.3, None, None)]:
+        got = frame_ops.binarize(dev, onset=onset, offset=offset, initial_state=init).cpu().numpy()
+        want = op.hysteresis(scores, onset=onset, offset=offset, initial_state=init)
+        assert got.dtype == np.uint8 and np.array_equal(got.astype(np.float64), want)
+
+
+def test_soft_reconstruction_bit_exact(gpu_device):
+    """reconstruct + to_diarization from SOFT scores (non-powerset models: speaker_diarization.py:687-691):
+    cluster max -> float32 overlap-add sum in chunk order -> top-count[t], identical to the oracle's."""
+    from oracle import pipeline as op
+    rng = np.random.default_rng(3)
+    C, F, S = 61, 589, 3
+    scores = rng.uniform(size=(C, F, S)).astype(np.float32)
+    hard = rng.integers(-2, 4, size=(C, S))
+    hard[hard == -1] = 0
+    hard[7] = -2                                  # a chunk with no assigned speaker at all
+    chunks, frames = op.SW(0.0, 10.0, 1.0), op.SW(0.0, 991 / 16000, 270 / 16000)
+    binar = (scores > 0.5).astype(np.float32)
+    count, cf = op.speaker_count(binar, chunks, frames)
+    for cap in (255, 1):
+        cnt = np.minimum(count, cap).astype(np.int8)
+        want = op.reconstruct(scores, chunks, hard.copy(), cnt, cf)
+        rec = frame_ops.Reconstructor(torch.from_numpy(scores).to(gpu_device),
+                                      SlidingWindow(start=0.0, duration=10.0, step=1.0),
+                                      SlidingWindow(start=0.0, duration=991 / 16000, step=270 / 16000),
+                                      hard, cnt)
+        got = rec.discretize().data
+        assert got.shape == want.shape and np.array_equal(got, want)

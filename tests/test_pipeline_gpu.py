@@ -123,3 +123,40 @@ def test_linkage_centroid_bit_exact_vs_scipy(gpu_device, n, d, dup, seed):
     assert got.shape == want.shape and got.dtype == np.float64
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
+
+
+def test_non_powerset_pipeline_matches_oracle(synthetic_models, gpu_device, tmp_path):
+    """a14: a multi-label segmentation checkpoint -- sigmoid scores out of the
+    classifier kernel, hysteresis thresholding (pipelines/speaker_diarization.py:599-606, utils/signal.py:
+    78-204) on the device, reconstruction from the raw scores -- against the oracle (itself pinned to the
+    reference's pipeline run on the same kind of checkpoint, tests/test_reference_pipeline.py)."""
+    import pyannote_audio_amd as pa
+    from conftest import north_star_ratio, write_pipeline_dir
+    from oracle.pipeline import diarize
+    from oracle.synthetic import calibrated_multilabel_pyannet, synth_conversation
+    seg_o = calibrated_multilabel_pyannet(calib_seconds=40.0)
+    _, emb_o = synthetic_models
+    write_pipeline_dir(tmp_path, seg_o, emb_o, powerset=False)
+    pipeline = pa.Pipeline.from_pretrained(str(tmp_path)).to(gpu_device)
+    assert not pipeline._segmentation.model.specifications.powerset
+    conv, _ = synth_conversation(23.0, seed=14)
+    seen = {}
+
+    def hook(name, artefact, file=None, **kw):
+        if artefact is not None and kw.get("total") is None:
+            seen[name] = np.array(getattr(artefact, "data", artefact), copy=True)
+
+    out = pipeline({"waveform": conv, "sample_rate": 16000, "uri": "conv"}, hook=hook)
+    want = diarize(seg_o, emb_o, conv, exclude_overlap=True, segmentation_threshold=0.5)
+    assert north_star_ratio("non_powerset_scores", seen["segmentation"], want.raw_segmentations) <= 1.0
+    assert np.array_equal(seen["speaker_counting"].reshape(-1), want.count.reshape(-1))
+    got = [(s.start, s.end, l) for s, _, l in out.speaker_diarization.itertracks(yield_label=True)]
+    assert got == want.diarization
+    gotx = [(s.start, s.end, l) for s, _, l in out.exclusive_speaker_diarization.itertracks(yield_label=True)]
+    assert gotx == want.exclusive_diarization
+    # the stand-alone model contract: (B, 1, N) -> (B, F, 3) sigmoid scores
+    model = pipeline._segmentation.model
+    chunk = conv[:, :160000][None]
+    with torch.inference_mode():
+        ref = seg_o(chunk)
+    assert north_star_ratio("non_powerset_forward", model(chunk.to(gpu_device)), ref) <= 1.0

@@ -226,3 +226,53 @@ def test_reference_binarize_equals_oracle(ref):
     ann = ref["signal"].Binarize(onset=0.5, offset=0.5, min_duration_on=0.0, min_duration_off=0.0)(swf)
     got = sorted((s.start, s.end, int(l)) for s, _, l in ann.itertracks(yield_label=True))
     assert got == sorted((s, e, int(l)) for s, e, _, l in want)
+
+
+def test_reference_binarize_function_equals_oracle(ref):
+    """`binarize` (utils/signal.py:78-204; hysteresis thresholding, ndarray and SlidingWindowFeature forms)
+    vs oracle.pipeline.hysteresis, incl. NaN scores, scores exactly on a threshold, every initial state."""
+    from oracle import pipeline as op
+    rng = np.random.default_rng(6)
+    scores = rng.uniform(size=(7, 120, 3)).astype(np.float32)
+    scores[2, 10:14, 1] = np.nan
+    scores[3, ::9, 0] = 0.6            # exactly on the onset
+    scores[4, ::7, 2] = 0.4            # exactly on the offset
+    SWF, SW = ref["core"].SlidingWindowFeature, ref["core"].SlidingWindow
+    swf = SWF(scores, SW(start=0.0, duration=10.0, step=1.0))
+    for onset, offset, init in [(0.5, None, False), (0.6, 0.4, None), (0.6, 0.4, True), (0.3, None, None)]:
+        want = ref["signal"].binarize(swf, onset=onset, offset=offset, initial_state=init).data
+        got = op.hysteresis(scores, onset=onset, offset=offset, initial_state=init)
+        assert want.shape == got.shape and np.array_equal(got, want)
+
+
+def test_reference_non_powerset_pipeline_equals_oracle(ref, tmp_path, models):
+    """a14: a multi-label (non-powerset) segmentation checkpoint through the reference's pipeline --
+    `binarize(segmentations, onset=threshold, initial_state=False)` (speaker_diarization.py:599-606), counting /
+    masks / clustering on the binary form, reconstruction from the RAW scores (:687-691) -- vs the oracle."""
+    import oracle.vbx as ov
+    from conftest import write_pipeline_dir
+    from oracle.pipeline import diarize
+    from oracle.synthetic import calibrated_multilabel_pyannet, synth_conversation
+    seg_o = calibrated_multilabel_pyannet(calib_seconds=40.0)
+    _, emb_o = models
+    d = str(tmp_path)
+    write_pipeline_dir(d, seg_o, emb_o, powerset=False)
+    ov.synth_plda(os.path.join(d, "plda"))
+    params = {"clustering": AHC_PARAMS["clustering"], "segmentation": {"threshold": 0.5, "min_duration_off": 0.0}}
+    pipe = _pipeline(ref, d, params=params)
+    conv, _ = synth_conversation(23.0, seed=14)
+    seen = {}
+
+    def hook(name, artefact, file=None, **kw):
+        if artefact is not None:
+            seen[name] = np.array(getattr(artefact, "data", artefact), copy=True)
+
+    out = pipe({"waveform": conv, "sample_rate": 16000, "uri": "conv"}, hook=hook)
+    want = diarize(seg_o, emb_o, conv, exclude_overlap=True, segmentation_threshold=0.5)
+    assert seen["segmentation"].dtype == np.float32 and 0.0 < seen["segmentation"].min() < 0.5
+    assert np.array_equal(seen["segmentation"], want.raw_segmentations)
+    assert np.array_equal(seen["speaker_counting"].reshape(-1), want.count.reshape(-1))
+    assert np.array_equal(seen["embeddings"], want.embeddings, equal_nan=True)
+    assert _turns(out.speaker_diarization) == want.diarization
+    assert _turns(out.exclusive_speaker_diarization) == want.exclusive_diarization
+    assert len(want.diarization) > 5 and len({l for _, _, l in want.diarization}) >= 2
