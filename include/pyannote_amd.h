@@ -182,6 +182,48 @@ int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* 
                   const int* nearest_idx, float* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * XVectorSincNet embedding model: replaces XVectorSincNet.forward (models/embedding/xvector.py:330-349) =
+ * SincNet -> 5 x (Conv1d(k, dilation) + LeakyReLU + BatchNorm1d) -> StatsPool(weights) -> Linear, as called
+ * by PyannoteAudioPretrainedSpeakerEmbedding (pipelines/speaker_verification.py:704-716).
+ * ---------------------------------------------------------------------------------------- */
+#define PA_XVEC_TDNN 5
+typedef struct pa_xvec_weights {
+  int32_t sinc_stride;                 /* 10 */
+  int32_t dimension;                   /* embedding size (512) */
+  int32_t tdnn_channels[PA_XVEC_TDNN]; /* 512, 512, 512, 512, 1500 (multiples of 4) */
+  int32_t tdnn_kernel[PA_XVEC_TDNN];   /* 5, 3, 3, 1, 1 */
+  int32_t tdnn_dilation[PA_XVEC_TDNN]; /* 1, 2, 3, 1, 1 */
+  float wav_gamma, wav_beta;           /* SincNet fields: exactly those of pa_seg_weights */
+  const float* sinc_filt;
+  const float* norm0;
+  const float* conv1_w;
+  const float* conv1_b;
+  const float* norm1;
+  const float* conv2_w;
+  const float* conv2_b;
+  const float* norm2;
+  /* [k][cout][cin_pad] per layer (cin_pad = 64 for layer 0), the PREVIOUS layer's BatchNorm folded in */
+  const float* tdnn_w[PA_XVEC_TDNN];
+  const float* tdnn_b[PA_XVEC_TDNN];
+  const float* emb_w; /* [dimension][ld] ld = 2 * channels[4] rounded up to 32, last BatchNorm folded in */
+  const float* emb_b;
+} pa_xvec_weights;
+
+/* frames left after SincNet and the TDNN stack (XVectorSincNet.num_frames, xvector.py:264-287); 0 = too short */
+int pa_xvec_num_frames(const pa_xvec_weights* w, int num_samples);
+size_t pa_xvec_workspace_bytes(const pa_xvec_weights* w, int num_chunks, int num_samples, int num_masks);
+/* chunks addressed like pa_seg_forward; masks (num_chunks, num_masks, mask_frames) fp32 or NULL (unweighted
+ * pooling), nearest_idx (frames) = F.interpolate(mode="nearest") source index of every pooled frame;
+ * emb: (num_chunks * num_masks, dimension) */
+int pa_xvec_forward(const pa_xvec_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                    int num_chunks, int num_samples, const float* masks, int num_masks, int mask_frames,
+                    const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* StatsPool over the rows of a (tile, t, b16)-ordered activation matrix (models/blocks/pooling.py:64-130) */
+int pa_stats_pool_rows(const float* feat, int B, int T0, int Tp, int C, int ld, const float* masks, int S,
+                       int Fm, const int* nearest_idx, float* stats, int ld_stats, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Clustering distances (fp64, bit-identical to SciPy): replace the pdist inside
  * scipy.cluster.hierarchy.linkage(X, "centroid", "euclidean") (pipelines/clustering.py:374-382) and
  * scipy.spatial.distance.cdist(E, centroids, "cosine") (pipelines/clustering.py:190-200).

@@ -38,4 +38,6 @@ from .models import (  # noqa: F401
     Powerset,
     seeded_pyannet,
     seeded_wespeaker,
+    XVectorSincNet,
+    seeded_xvector,
 )

@@ -452,6 +452,52 @@ class WeSpeakerResNet34(nn.Module):
         return self.resnet(self.compute_fbank(waveforms), weights=weights)
 
 
+class XVectorSincNet(nn.Module):
+    """SincNet -> 5 x (Conv1d + LeakyReLU + BatchNorm1d) -> StatsPool -> Linear
+    (models/embedding/xvector.py:205-349; pinned bit for bit to that class by
+    tests/test_reference_pipeline.py)."""
+
+    def __init__(self, sample_rate: int = 16000, dimension: int = 512, stride: int = 10):
+        super().__init__()
+        self.sincnet = SincNet(sample_rate=sample_rate, stride=stride)
+        self.tdnns = nn.ModuleList()
+        in_channel = 60
+        for out_channel, kernel_size, dilation in zip([512, 512, 512, 512, 1500], [5, 3, 3, 1, 1],
+                                                      [1, 2, 3, 1, 1]):
+            self.tdnns.extend([nn.Conv1d(in_channel, out_channel, kernel_size, dilation=dilation),
+                               nn.LeakyReLU(), nn.BatchNorm1d(out_channel)])
+            in_channel = out_channel
+        self.stats_pool = StatsPool()
+        self.embedding = nn.Linear(in_channel * 2, dimension)
+
+    def forward(self, waveforms, weights=None):
+        outputs = self.sincnet(waveforms).squeeze(dim=1)
+        for tdnn in self.tdnns:
+            outputs = tdnn(outputs)
+        return self.embedding(self.stats_pool(outputs, weights=weights))
+
+
+def seeded_xvector(seed: int = 2468, dimension: int = 512) -> XVectorSincNet:
+    """Default-initialised XVectorSincNet with randomised BatchNorm statistics / affine and SincNet norms."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    model = XVectorSincNet(dimension=dimension)
+    with torch.no_grad():
+        sn = model.sincnet
+        sn.wav_norm1d.weight.copy_(1.0 + 0.1 * torch.randn(1, generator=g))
+        sn.wav_norm1d.bias.copy_(0.1 * torch.randn(1, generator=g))
+        for n in sn.norm1d:
+            n.weight.copy_(1.0 + 0.2 * torch.randn(n.weight.shape, generator=g))
+            n.bias.copy_(0.2 * torch.randn(n.bias.shape, generator=g))
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    return model.eval()
+
+
 # --------------------------------------------------------------------------------------
 # seeded synthetic weights (SURVEY.md section 8d: no pretrained checkpoints are available)
 # --------------------------------------------------------------------------------------

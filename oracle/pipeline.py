@@ -391,7 +391,7 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
             segmentation_batch_size: int = 32, embedding_batch_size: int = 32,
             num_speakers=None, min_speakers=None, max_speakers=None,
             method="centroid", threshold=0.7045654963945799, min_cluster_size=12,
-            segmentation_threshold: float = 0.5) -> OracleOutput:
+            segmentation_threshold: float = 0.5, min_num_samples: int = 400) -> OracleOutput:
     """SpeakerDiarization.apply (speaker_diarization.py:530-784) for the 3.1 configuration."""
     import time
     timings = {}
@@ -415,7 +415,8 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
         return OracleOutput([], [], np.zeros((0, 256)), segmentations, count, None, None, timings)
     t0 = time.perf_counter()
     embeddings = get_embeddings(emb_model, waveform, segmentations, chunks, sample_rate,
-                                exclude_overlap=exclude_overlap, batch_size=embedding_batch_size)
+                                exclude_overlap=exclude_overlap, batch_size=embedding_batch_size,
+                                min_num_samples=min_num_samples)
     timings["embeddings"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     hard_clusters, _, centroids = clustering(

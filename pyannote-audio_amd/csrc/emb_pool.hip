@@ -78,9 +78,98 @@ __global__ __launch_bounds__(256) void k_stats_pool(const float* __restrict__ fe
     }
 }
 
+// The same pooling over the rows of a (tile, t, b16)-ordered activation matrix (the row order of the
+// segmentation / x-vector stacks: row(b, t) = ((b >> 4) * T0 + t) * 16 + (b & 15), `ld` floats per row):
+// StatsPool of XVectorSincNet (models/embedding/xvector.py:343-348, models/blocks/pooling.py:64-130).
+// stats[b][s][ld_stats]: mean (C) | std (C) | zero padding up to ld_stats.  masks == NULL: the unweighted
+// form, mean and std(correction = 1) (pooling.py:101-104).
+constexpr int POOLR_MAXT = 640;
+
+__global__ __launch_bounds__(256) void k_stats_pool_rows(const float* __restrict__ feat, int T0, int Tp, int Cc,
+                                                         int ld, const float* __restrict__ masks, int S, int Fm,
+                                                         const int* __restrict__ idx, float* __restrict__ stats,
+                                                         int ld_stats) {
+  __shared__ float ws[POOL_MAXS][POOLR_MAXT];
+  __shared__ float v1s[POOL_MAXS], dens[POOL_MAXS];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < S * Tp; i += 256) {
+    const int s = i / Tp, t = i % Tp;
+    ws[s][t] = masks != nullptr ? masks[((long)b * S + s) * Fm + idx[t]] : 1.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < S) {
+    const int s = threadIdx.x;
+    float a = 0.f, q = 0.f;
+    for (int t = 0; t < Tp; ++t) {
+      a += ws[s][t];
+      q += ws[s][t] * ws[s][t];
+    }
+    if (masks != nullptr) {
+      const float v1 = a + 1e-8f;
+      v1s[s] = v1;
+      dens[s] = v1 - q / v1 + 1e-8f;
+    } else {
+      v1s[s] = (float)Tp;
+      dens[s] = (float)(Tp - 1);   // 0 for a single frame: std = NaN, as torch.std(correction=1)
+    }
+  }
+  __syncthreads();
+  // padding columns of the output row (the embedding GEMM reads K rounded up to 32)
+  for (int i = 2 * Cc + threadIdx.x + blockIdx.x * 256; i < ld_stats; i += 256 * gridDim.x)
+    for (int s = 0; s < S; ++s) stats[((long)b * S + s) * ld_stats + i] = 0.f;
+  if (c >= Cc) return;
+  const float* x = feat + (((long)(b >> 4) * T0) * 16 + (b & 15)) * ld + c;
+  const long ts = 16L * ld;
+  float m[POOL_MAXS];
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s) m[s] = 0.f;
+  for (int t = 0; t < Tp; ++t) {
+    const float xv = x[t * ts];
+#pragma unroll
+    for (int s = 0; s < POOL_MAXS; ++s)
+      if (s < S) m[s] = fmaf(xv, ws[s][t], m[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s)
+    if (s < S) m[s] /= v1s[s];
+  float v[POOL_MAXS];
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s) v[s] = 0.f;
+  for (int t = 0; t < Tp; ++t) {
+    const float xv = x[t * ts];
+#pragma unroll
+    for (int s = 0; s < POOL_MAXS; ++s)
+      if (s < S) {
+        const float d = xv - m[s];
+        v[s] = fmaf(d * d, ws[s][t], v[s]);
+      }
+  }
+#pragma unroll
+  for (int s = 0; s < POOL_MAXS; ++s)
+    if (s < S) {
+      float* o = stats + ((long)b * S + s) * ld_stats;
+      o[c] = m[s];
+      o[Cc + c] = sqrtf(v[s] / dens[s]);
+    }
+}
+
 }  // namespace pa
 
 extern "C" {
+
+int pa_stats_pool_rows(const float* feat, int B, int T0, int Tp, int C, int ld, const float* masks, int S,
+                       int Fm, const int* nearest_idx, float* stats, int ld_stats, void* stream) {
+  if (B <= 0) return 0;
+  PA_REQUIRE(S >= 1 && S <= pa::POOL_MAXS && Tp >= 1 && Tp <= pa::POOLR_MAXT && ld_stats >= 2 * C,
+             "pa_stats_pool_rows: S <= %d, 1 <= T' <= %d and ld_stats >= 2 C required (got %d, %d)",
+             pa::POOL_MAXS, pa::POOLR_MAXT, S, Tp);
+  pa::ProfScope prof("k_stats_pool_rows", stream, 6.0 * B * S * C * Tp, 4.0 * B * C * Tp + 8.0 * B * S * C);
+  hipLaunchKernelGGL(pa::k_stats_pool_rows, dim3(pa::cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, feat,
+                     T0, Tp, C, ld, masks, S, Fm, nearest_idx, stats, ld_stats);
+  PA_CHECK_LAUNCH("pa_stats_pool_rows");
+  return 0;
+}
 
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream) {

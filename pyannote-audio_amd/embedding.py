@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ffi
-from .weights import EmbeddingPack
+from .weights import EmbeddingPack, XVectorPack
 
 
 class EmbeddingEngine:
@@ -88,3 +88,46 @@ class EmbeddingEngine:
             m = weights.unsqueeze(1) if weights.dim() == 2 else weights
         emb = self.forward_strided(x, N, B, N, m)
         return emb[:, 0] if squeeze else emb
+
+
+class XVectorEngine(EmbeddingEngine):
+    """XVectorSincNet (models/embedding/xvector.py:205-349) over `pa_xvec_forward`: SincNet -> 5 TDNN layers
+    -> weighted statistics pooling -> Linear; same strided-chunk / all-masks-at-once interface."""
+
+    def __init__(self, pack: XVectorPack, max_chunks: Optional[int] = None):
+        self.pack = pack
+        self.max_chunks = max_chunks or 512      # ~5.3 MB of activations per 10 s chunk
+        self._ws = None
+        self._idx_cache = {}
+
+    def num_pool_frames(self, num_samples: int) -> int:
+        return ffi.load().pa_xvec_num_frames(self.pack.struct, num_samples)
+
+    @ffi.on_device(lambda self, *a, **k: self.pack.device)
+    def forward_strided(self, wav: torch.Tensor, chunk_stride: int, num_chunks: int, num_samples: int,
+                        masks: torch.Tensor | None = None) -> torch.Tensor:
+        lib = ffi.load()
+        w = self.pack.struct
+        dev = self.pack.device
+        Tp = self.num_pool_frames(num_samples)
+        if Tp < 1:
+            raise ValueError(f"chunks of {num_samples} samples are too short for SincNet + the TDNN stack")
+        S = 1 if masks is None else masks.shape[1]
+        Fm = 0 if masks is None else masks.shape[2]
+        idx = self.nearest_index(Fm, Tp) if masks is not None else None
+        if masks is not None:
+            masks = masks.to(dev, torch.float32).contiguous()
+        emb = torch.empty((num_chunks, S, w.dimension), dtype=torch.float32, device=dev)
+        c0 = 0
+        while c0 < num_chunks:
+            nb = min(self.max_chunks, num_chunks - c0)
+            ws = self._workspace(lib.pa_xvec_workspace_bytes(w, nb, num_samples, S))
+            sub = wav[c0 * chunk_stride:]
+            rc = lib.pa_xvec_forward(
+                w, ffi.c_fp(sub.data_ptr()), sub.numel(), chunk_stride, nb, num_samples,
+                ffi.ptr(masks[c0:c0 + nb]) if masks is not None else None, S, Fm,
+                ffi.ptr(idx) if idx is not None else None, ffi.ptr(emb[c0:c0 + nb]),
+                ffi.ptr(ws), ws.numel(), ffi.stream())
+            ffi.check(rc, "pa_xvec_forward")
+            c0 += nb
+        return emb

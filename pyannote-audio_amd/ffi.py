@@ -51,6 +51,23 @@ class EmbWeights(C.Structure):
     ]
 
 
+PA_XVEC_TDNN = 5
+
+
+class XvecWeights(C.Structure):
+    """pa_xvec_weights (include/pyannote_amd.h)"""
+    _fields_ = [
+        ("sinc_stride", C.c_int32), ("dimension", C.c_int32),
+        ("tdnn_channels", C.c_int32 * PA_XVEC_TDNN), ("tdnn_kernel", C.c_int32 * PA_XVEC_TDNN),
+        ("tdnn_dilation", C.c_int32 * PA_XVEC_TDNN),
+        ("wav_gamma", C.c_float), ("wav_beta", C.c_float),
+        ("sinc_filt", c_fp), ("norm0", c_fp), ("conv1_w", c_fp), ("conv1_b", c_fp), ("norm1", c_fp),
+        ("conv2_w", c_fp), ("conv2_b", c_fp), ("norm2", c_fp),
+        ("tdnn_w", c_fp * PA_XVEC_TDNN), ("tdnn_b", c_fp * PA_XVEC_TDNN),
+        ("emb_w", c_fp), ("emb_b", c_fp),
+    ]
+
+
 class LibraryNotBuilt(RuntimeError):
     pass
 
@@ -145,6 +162,12 @@ _OPTIONAL: list[tuple] = [
                           c_fp, C.c_size_t, c_fp], C.c_int),
     ("pa_stats_pool", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp,
                        c_fp], C.c_int),
+    ("pa_stats_pool_rows", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp,
+                            c_fp, C.c_int, c_fp], C.c_int),
+    ("pa_xvec_num_frames", [C.POINTER(XvecWeights), C.c_int], C.c_int),
+    ("pa_xvec_workspace_bytes", [C.POINTER(XvecWeights), C.c_int, C.c_int, C.c_int], C.c_size_t),
+    ("pa_xvec_forward", [C.POINTER(XvecWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int, c_fp,
+                         C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_size_t, c_fp], C.c_int),
 ]
 
 

@@ -309,11 +309,11 @@ class Model:
         arch = ckpt["pyannote.audio"]["architecture"]["class"]
         klass = {"PyanNet": PyanNet, "WeSpeakerResNet34": WeSpeakerResNet34,
                  "WeSpeakerResNet152": WeSpeakerResNet152, "WeSpeakerResNet221": WeSpeakerResNet221,
-                 "WeSpeakerResNet293": WeSpeakerResNet293}.get(arch)
+                 "WeSpeakerResNet293": WeSpeakerResNet293, "XVectorSincNet": XVectorSincNet}.get(arch)
         if klass is None:
             raise NotImplementedError(
                 f"architecture {arch!r} is outside the accelerated hot path (PyanNet, "
-                "WeSpeakerResNet34/152/221/293)")
+                "WeSpeakerResNet34/152/221/293, XVectorSincNet)")
         return klass(ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {})),
                      ckpt["pyannote.audio"]["specifications"])
 
@@ -423,6 +423,43 @@ class WeSpeakerResNet34(Model):
         from .weights import EmbeddingPack
         return EmbeddingEngine(EmbeddingPack(self._state_dict, device,
                                              sample_rate=self.audio.sample_rate))
+
+    def __call__(self, waveforms: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.engine.forward(waveforms, weights)
+
+    forward = __call__
+
+
+class XVectorSincNet(Model):
+    """models/embedding/xvector.py:205-349 over the HIP x-vector engine."""
+
+    ARCHITECTURE = ("pyannote.audio.models.embedding.xvector", "XVectorSincNet")
+    _TDNN = ([5, 3, 3, 1, 1], [1, 1, 1, 1, 1], [0, 0, 0, 0, 0], [1, 2, 3, 1, 1])   # kernel, stride, pad, dilation
+    _K = [251, 3, 5, 3, 5, 3]
+
+    def _sinc(self):
+        s = int((self.hparams.get("sincnet") or {}).get("stride", 10))
+        return self._K, [s, 3, 1, 3, 1, 3], [0] * 6, [1] * 6
+
+    @property
+    def dimension(self) -> int:
+        return int(self._state_dict["embedding.weight"].shape[0])
+
+    def num_frames(self, num_samples: int) -> int:
+        return multi_conv_num_frames(multi_conv_num_frames(num_samples, *self._sinc()), *self._TDNN)
+
+    def receptive_field_size(self, num_frames: int = 1) -> int:
+        return multi_conv_receptive_field_size(multi_conv_receptive_field_size(num_frames, *self._TDNN),
+                                               *self._sinc())
+
+    def receptive_field_center(self, frame: int = 0) -> int:
+        return multi_conv_receptive_field_center(multi_conv_receptive_field_center(frame, *self._TDNN),
+                                                 *self._sinc())
+
+    def _build_engine(self, device):
+        from .embedding import XVectorEngine
+        from .weights import XVectorPack
+        return XVectorEngine(XVectorPack(self._state_dict, dict(self.hparams), device))
 
     def __call__(self, waveforms: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.engine.forward(waveforms, weights)

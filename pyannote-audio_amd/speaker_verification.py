@@ -84,8 +84,12 @@ class PyannoteAudioPretrainedSpeakerEmbedding(BaseInference):
         shorter and shorter random inputs until it raises (:688-702); here the only failure mode is
         "shorter than one fbank frame", which the C ABI answers directly (`pa_emb_num_fbank_frames`)."""
         if self._min_num_samples is None:
-            frames = ffi.load().pa_emb_num_fbank_frames
-            self._min_num_samples = first_true(lambda n: frames(n) > 0, 2, round(0.5 * self.sample_rate))
+            if hasattr(self.model_, "_TDNN"):     # x-vector: SincNet + TDNN must leave at least one frame
+                enough = lambda n: self.model_.num_frames(n) > 0   # noqa: E731
+            else:
+                frames = ffi.load().pa_emb_num_fbank_frames
+                enough = lambda n: frames(n) > 0                   # noqa: E731
+            self._min_num_samples = first_true(enough, 2, round(0.5 * self.sample_rate))
         return self._min_num_samples
 
     def __call__(self, waveforms: torch.Tensor, masks: Optional[torch.Tensor] = None) -> np.ndarray:

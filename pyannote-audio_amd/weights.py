@@ -111,29 +111,11 @@ class SegmentationPack:
         self.device = device
         self._keep: list[torch.Tensor] = []
         w = ffi.SegWeights()
-        w.sinc_stride = 10
         w.lstm_layers = L = int(lstm["num_layers"])
         w.lstm_hidden, w.lstm_bidir = 128, 1
         w.num_linear, w.linear_hidden = int(linear["num_layers"]), 128
         w.num_classes, w.num_speakers = num_classes, num_speakers
-        w.wav_gamma = float(sd["sincnet.wav_norm1d.weight"][0])
-        w.wav_beta = float(sd["sincnet.wav_norm1d.bias"][0])
-
-        taps = sinc_filters(sd["sincnet.conv1d.0.filterbank.low_hz_"],
-                            sd["sincnet.conv1d.0.filterbank.band_hz_"])
-        self.sinc_taps = taps  # (80, 251) kept for tests
-        w.sinc_filt = self._up(_mfma_b_image(torch.nn.functional.pad(taps, (0, 1)), 5))
-        for i, c in enumerate((80, 60, 60)):
-            nb = torch.cat([sd[f"sincnet.norm1d.{i}.weight"], sd[f"sincnet.norm1d.{i}.bias"]])
-            setattr(w, f"norm{i}", self._up(nb))
-        for i, cin in ((1, 80), (2, 60)):
-            cw = sd[f"sincnet.conv1d.{i}.weight"]  # (60, cin, 5)
-            wk = torch.zeros(64, 5 * cin)
-            wk[:60] = cw.permute(0, 2, 1).reshape(60, 5 * cin)  # k = tap*cin + c
-            setattr(w, f"conv{i}_w", self._up(_mfma_b_image(wk, 4)))
-            cb = torch.zeros(64)
-            cb[:60] = sd[f"sincnet.conv1d.{i}.bias"]
-            setattr(w, f"conv{i}_b", self._up(cb))
+        self.sinc_taps = pack_sincnet(sd, w, self._up)  # (80, 251) kept for tests
 
         perm = _lstm_row_perm()
         for l in range(L):
@@ -167,6 +149,85 @@ class SegmentationPack:
             assert num_classes == num_speakers
             self.mapping = None
             w.powerset_map = None
+        self.struct = w
+
+    def _up(self, t: torch.Tensor):
+        d = t.contiguous().to(self.device)
+        self._keep.append(d)
+        return C.c_void_p(d.data_ptr())
+
+
+def pack_sincnet(sd: dict, w, up) -> torch.Tensor:
+    """SincNet weights (models/blocks/sincnet.py:40-80) -> the MFMA operand images shared by
+    pa_seg_weights and pa_xvec_weights; returns the (80, 251) taps."""
+    w.sinc_stride = 10
+    w.wav_gamma = float(sd["sincnet.wav_norm1d.weight"][0])
+    w.wav_beta = float(sd["sincnet.wav_norm1d.bias"][0])
+    taps = sinc_filters(sd["sincnet.conv1d.0.filterbank.low_hz_"], sd["sincnet.conv1d.0.filterbank.band_hz_"])
+    w.sinc_filt = up(_mfma_b_image(torch.nn.functional.pad(taps, (0, 1)), 5))
+    for i, c in enumerate((80, 60, 60)):
+        setattr(w, f"norm{i}", up(torch.cat([sd[f"sincnet.norm1d.{i}.weight"], sd[f"sincnet.norm1d.{i}.bias"]])))
+    for i, cin in ((1, 80), (2, 60)):
+        cw = sd[f"sincnet.conv1d.{i}.weight"]  # (60, cin, 5)
+        wk = torch.zeros(64, 5 * cin)
+        wk[:60] = cw.permute(0, 2, 1).reshape(60, 5 * cin)  # k = tap*cin + c
+        setattr(w, f"conv{i}_w", up(_mfma_b_image(wk, 4)))
+        cb = torch.zeros(64)
+        cb[:60] = sd[f"sincnet.conv1d.{i}.bias"]
+        setattr(w, f"conv{i}_b", up(cb))
+    return taps
+
+
+class XVectorPack:
+    """Device-resident, kernel-ready XVectorSincNet weights + the `pa_xvec_weights` struct
+    (models/embedding/xvector.py:205-252).  State-dict layout: sincnet.*, tdnns.{3l}.{weight,bias} (Conv1d),
+    tdnns.{3l+2}.{weight,bias,running_mean,running_var} (BatchNorm1d, eval), embedding.{weight,bias}.
+    Every BatchNorm follows a LeakyReLU, so it cannot be folded backwards; being an affine map it is folded
+    FORWARD, in float64: into the next convolution (W_j diag(s), b + sum_j W_j t) and, for the last one,
+    through the statistics pooling (mean -> s mean + t, std -> |s| std) into the embedding Linear."""
+
+    KERNEL, DILATION = (5, 3, 3, 1, 1), (1, 2, 3, 1, 1)
+
+    def __init__(self, state_dict: dict, hparams: dict, device: torch.device):
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
+        if int((hparams.get("sincnet") or {}).get("stride", 10)) != 10:
+            raise NotImplementedError("kernels are built for SincNet stride 10")
+        self.device = device
+        self._keep: list[torch.Tensor] = []
+        w = ffi.XvecWeights()
+        self.sinc_taps = pack_sincnet(sd, w, self._up)
+        self.folded_tdnn: list = []                # [(taps (k, cout, cin_pad), bias (cout))] kept for tests
+        scale = shift = None                       # affine map of the previous BatchNorm (float64)
+        for l in range(ffi.PA_XVEC_TDNN):
+            cw = sd[f"tdnns.{3 * l}.weight"].double()          # (cout, cin, k)
+            cb = sd[f"tdnns.{3 * l}.bias"].double()
+            cout, cin, k = cw.shape
+            if k != self.KERNEL[l] or cout % 4:
+                raise NotImplementedError(f"unexpected TDNN layer {l}: {tuple(cw.shape)}")
+            if scale is not None:
+                cb = cb + torch.einsum("oik,i->o", cw, shift)
+                cw = cw * scale.view(1, -1, 1)
+            cin_pad = 64 if l == 0 else cin
+            taps = torch.zeros(k, cout, cin_pad, dtype=torch.float64)
+            taps[:, :, :cin] = cw.permute(2, 0, 1)
+            w.tdnn_w[l] = self._up(taps.float()).value
+            w.tdnn_b[l] = self._up(cb.float()).value
+            self.folded_tdnn.append((self._keep[-2], self._keep[-1]))
+            w.tdnn_channels[l], w.tdnn_kernel[l], w.tdnn_dilation[l] = cout, k, self.DILATION[l]
+            bn = f"tdnns.{3 * l + 2}"
+            scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + 1e-5)
+            shift = sd[bn + ".bias"].double() - sd[bn + ".running_mean"].double() * scale
+        ew, eb = sd["embedding.weight"].double(), sd["embedding.bias"].double()
+        C_ = int(w.tdnn_channels[ffi.PA_XVEC_TDNN - 1])
+        assert ew.shape[1] == 2 * C_
+        eb = eb + ew[:, :C_] @ shift
+        ld = (2 * C_ + 31) // 32 * 32
+        packed = torch.zeros(ew.shape[0], ld, dtype=torch.float64)
+        packed[:, :C_] = ew[:, :C_] * scale
+        packed[:, C_:2 * C_] = ew[:, C_:] * scale.abs()
+        w.emb_w, w.emb_b = self._up(packed.float()), self._up(eb.float())
+        self.folded_embedding = (self._keep[-2], self._keep[-1])
+        w.dimension = int(ew.shape[0])
         self.struct = w
 
     def _up(self, t: torch.Tensor):

@@ -76,8 +76,15 @@ def write_pipeline_dir(root, seg_model, emb_model, config_extra=None, powerset=T
     os.makedirs(os.path.join(root, "embedding"), exist_ok=True)
     save_checkpoint(os.path.join(root, "segmentation", "pytorch_model.bin"), seg_model.state_dict(),
                     PYANNET_HPARAMS, PyanNet.ARCHITECTURE, segmentation_specifications(10.0, powerset))
-    save_checkpoint(os.path.join(root, "embedding", "pytorch_model.bin"), emb_model.state_dict(),
-                    WESPEAKER_HPARAMS, WeSpeakerResNet34.ARCHITECTURE, embedding_specifications())
+    if hasattr(emb_model, "tdnns"):        # XVectorSincNet (models/embedding/xvector.py:205-252)
+        from pyannote_audio_amd.model import XVectorSincNet
+        save_checkpoint(os.path.join(root, "embedding", "pytorch_model.bin"), emb_model.state_dict(),
+                        {"sincnet": {"stride": 10, "sample_rate": 16000}, "dimension": emb_model.embedding.out_features,
+                         "sample_rate": 16000, "num_channels": 1},
+                        XVectorSincNet.ARCHITECTURE, embedding_specifications())
+    else:
+        save_checkpoint(os.path.join(root, "embedding", "pytorch_model.bin"), emb_model.state_dict(),
+                        WESPEAKER_HPARAMS, WeSpeakerResNet34.ARCHITECTURE, embedding_specifications())
     config = {
         "version": "3.1.0",
         "pipeline": {"name": "pyannote.audio.pipelines.SpeakerDiarization",

@@ -325,7 +325,7 @@ def _signal_standins() -> dict:
     compliance = _module("torchaudio.compliance", kaldi=kaldi)
     compliance.__path__ = []
     functional = _module("torchaudio.functional", resample=oaudio.resample)
-    transforms = _module("torchaudio.transforms")
+    transforms = _module("torchaudio.transforms", MFCC=_Anything)     # (XVectorMFCC is not on the path)
     torchaudio = _module("torchaudio", compliance=compliance, functional=functional, transforms=transforms)
     torchaudio.__path__ = []
     return {"asteroid_filterbanks": asteroid, "torchaudio": torchaudio, "torchaudio.compliance": compliance,

@@ -64,15 +64,16 @@ def test_struct_layout_matches_header():
     """ctypes mirror of pa_seg_weights / pa_emb_weights has the size the C compiler gives."""
     import subprocess, tempfile
     import pyannote_audio_amd.ffi as ffi
-    src = '#include <stdio.h>\n#include "pyannote_amd.h"\nint main(){printf("%zu %zu\\n", sizeof(pa_seg_weights), sizeof(pa_emb_weights));return 0;}\n'
+    src = '#include <stdio.h>\n#include "pyannote_amd.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(pa_seg_weights), sizeof(pa_emb_weights), sizeof(pa_xvec_weights));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        a, b = map(int, subprocess.check_output([exe]).split())
+        a, b, c = map(int, subprocess.check_output([exe]).split())
     assert ctypes.sizeof(ffi.SegWeights) == a
     assert ctypes.sizeof(ffi.EmbWeights) == b
+    assert ctypes.sizeof(ffi.XvecWeights) == c
 
 
 def test_no_cpu_fallback():

@@ -238,3 +238,29 @@ def test_optimal_mapping_onto_reference_speakers():
     _, mapping = optimal_mapping(file, hyp, return_mapping=True)
     assert mapping == {1: "bob"}         # inside [9, 12] only speaker 1 overlaps anybody (1 s alice, 2 s bob)
     assert optimal_mapping(ref, pa.Annotation(uri="empty")).labels() == []
+
+
+def test_xvector_pack_folds_batchnorm_forward():
+    """XVectorPack (weights.py): every BatchNorm1d of the TDNN stack follows a LeakyReLU, so it is folded into
+    the NEXT convolution and, for the last one, through the statistics pooling into the embedding Linear.
+    The folded chain, evaluated with plain torch ops, equals the oracle module (xvector.py:330-349)."""
+    import torch.nn.functional as F
+    from oracle import seeded_xvector
+    from pyannote_audio_amd.weights import XVectorPack
+    model = seeded_xvector()
+    pack = XVectorPack(model.state_dict(), {"sincnet": {"stride": 10}}, torch.device("cpu"))
+    g = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(2, 1, 32000, generator=g)).clamp(-1, 1)
+    w = (torch.rand(2, 117, generator=g) < 0.6).float()
+    with torch.inference_mode():
+        want = model(wav, weights=w)
+        x = model.sincnet(wav)                                        # (B, 60, T)
+        x = F.pad(x, (0, 0, 0, 4))                                    # channels 60 -> 64 (zero)
+        for (taps, bias), d in zip(pack.folded_tdnn, XVectorPack.DILATION):
+            k, cout, cin = taps.shape
+            x = F.leaky_relu(F.conv1d(x, taps.permute(1, 2, 0).contiguous(), bias, dilation=d))
+        stats = model.stats_pool(x, weights=w)                        # mean | std of the UN-normalised output
+        ew, eb = pack.folded_embedding
+        got = stats @ ew[:, :stats.shape[1]].T + eb
+    assert ew.shape[1] == 3008 and torch.count_nonzero(ew[:, 3000:]) == 0
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)

@@ -276,3 +276,43 @@ def test_reference_non_powerset_pipeline_equals_oracle(ref, tmp_path, models):
     assert _turns(out.speaker_diarization) == want.diarization
     assert _turns(out.exclusive_speaker_diarization) == want.exclusive_diarization
     assert len(want.diarization) > 5 and len({l for _, _, l in want.diarization}) >= 2
+
+
+def test_reference_xvector_sincnet_equals_oracle(ref):
+    """f3: `XVectorSincNet` (models/embedding/xvector.py:205-349) from the reference vs oracle.models.
+    XVectorSincNet with the same state dict: same keys, identical embeddings with / without weights, the
+    reference's frame geometry and the `min_num_samples` bisection of the pipeline wrapper
+    (pipelines/speaker_verification.py:688-702) reproduced by the product's closed form."""
+    import oracle.models as om
+    import pyannote_audio_amd.model as pm
+    xv = ref["r"].load("pyannote.audio.models.embedding.xvector")
+    ours = om.seeded_xvector()
+    theirs = xv.XVectorSincNet()
+    assert list(theirs.state_dict()) == list(ours.state_dict())
+    theirs.load_state_dict(ours.state_dict())
+    theirs.eval()
+    g = torch.Generator().manual_seed(2)
+    wav = (0.1 * torch.randn(2, 1, 48000, generator=g)).clamp(-1, 1)
+    weights = (torch.rand(2, 173, generator=g) < 0.6).float()
+    with torch.inference_mode():
+        assert torch.equal(ours(wav, weights=weights), theirs(wav, weights=weights))
+        assert torch.equal(ours(wav), theirs(wav))
+    assert theirs.dimension == 512
+    product = pm.XVectorSincNet.__new__(pm.XVectorSincNet)
+    product.hparams = {"sincnet": {"stride": 10}}
+    for n in (4771, 4770, 48000, 80000, 160000):
+        assert product.num_frames(n) == theirs.num_frames(n)
+    assert product.receptive_field_size(1) == theirs.receptive_field_size(1)
+    assert product.receptive_field_center(0) == theirs.receptive_field_center(0)
+    # the wrapper's bisection: shortest waveform the reference model embeds without raising
+    lower, upper = 2, 8000
+    with torch.inference_mode():
+        while lower + 1 < upper:
+            middle = (lower + upper) // 2
+            try:
+                theirs(torch.randn(1, 1, middle))
+                upper = middle
+            except Exception:
+                lower = middle
+    from pyannote_audio_amd.speaker_verification import first_true
+    assert upper == first_true(lambda n: product.num_frames(n) > 0, 2, 8000)
