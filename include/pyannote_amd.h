@@ -205,7 +205,9 @@ typedef struct pa_xvec_weights {
   /* [k][cout][cin_pad] per layer (cin_pad = 64 for layer 0), the PREVIOUS layer's BatchNorm folded in */
   const float* tdnn_w[PA_XVEC_TDNN];
   const float* tdnn_b[PA_XVEC_TDNN];
-  const float* emb_w; /* [dimension][ld] ld = 2 * channels[4] rounded up to 32, last BatchNorm folded in */
+  const float* bn_scale; /* [channels[4]] the LAST BatchNorm as an affine map, applied inside the pooling */
+  const float* bn_shift;
+  const float* emb_w; /* [dimension][ld] ld = 2 * channels[4] rounded up to 32 (zero padded) */
   const float* emb_b;
 } pa_xvec_weights;
 
@@ -221,7 +223,9 @@ int pa_xvec_forward(const pa_xvec_weights* w, const float* wav, int64_t wav_len,
                     void* stream);
 /* StatsPool over the rows of a (tile, t, b16)-ordered activation matrix (models/blocks/pooling.py:64-130) */
 int pa_stats_pool_rows(const float* feat, int B, int T0, int Tp, int C, int ld, const float* masks, int S,
-                       int Fm, const int* nearest_idx, float* stats, int ld_stats, void* stream);
+                       int Fm, const int* nearest_idx, float* stats, int ld_stats,
+                       const float* aff_scale /* (C) or NULL: x -> scale x + shift on load */,
+                       const float* aff_shift, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Clustering distances (fp64, bit-identical to SciPy): replace the pdist inside

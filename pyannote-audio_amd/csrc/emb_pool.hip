@@ -88,7 +88,8 @@ constexpr int POOLR_MAXT = 640;
 __global__ __launch_bounds__(256) void k_stats_pool_rows(const float* __restrict__ feat, int T0, int Tp, int Cc,
                                                          int ld, const float* __restrict__ masks, int S, int Fm,
                                                          const int* __restrict__ idx, float* __restrict__ stats,
-                                                         int ld_stats) {
+                                                         int ld_stats, const float* __restrict__ aff_scale,
+                                                         const float* __restrict__ aff_shift) {
   __shared__ float ws[POOL_MAXS][POOLR_MAXT];
   __shared__ float v1s[POOL_MAXS], dens[POOL_MAXS];
   const int b = blockIdx.y;
@@ -121,11 +122,14 @@ __global__ __launch_bounds__(256) void k_stats_pool_rows(const float* __restrict
   if (c >= Cc) return;
   const float* x = feat + (((long)(b >> 4) * T0) * 16 + (b & 15)) * ld + c;
   const long ts = 16L * ld;
+  // per-channel affine map applied on load (the eval-mode BatchNorm1d that precedes the pooling,
+  // xvector.py:245: it cannot be folded past the pooling because an all-zero mask pools to 0, not to `shift`)
+  const float sc = aff_scale != nullptr ? aff_scale[c] : 1.f, sh = aff_shift != nullptr ? aff_shift[c] : 0.f;
   float m[POOL_MAXS];
 #pragma unroll
   for (int s = 0; s < POOL_MAXS; ++s) m[s] = 0.f;
   for (int t = 0; t < Tp; ++t) {
-    const float xv = x[t * ts];
+    const float xv = fmaf(x[t * ts], sc, sh);
 #pragma unroll
     for (int s = 0; s < POOL_MAXS; ++s)
       if (s < S) m[s] = fmaf(xv, ws[s][t], m[s]);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void k_stats_pool_rows(const float* __restrict
 #pragma unroll
   for (int s = 0; s < POOL_MAXS; ++s) v[s] = 0.f;
   for (int t = 0; t < Tp; ++t) {
-    const float xv = x[t * ts];
+    const float xv = fmaf(x[t * ts], sc, sh);
 #pragma unroll
     for (int s = 0; s < POOL_MAXS; ++s)
       if (s < S) {
@@ -159,14 +163,15 @@ __global__ __launch_bounds__(256) void k_stats_pool_rows(const float* __restrict
 extern "C" {
 
 int pa_stats_pool_rows(const float* feat, int B, int T0, int Tp, int C, int ld, const float* masks, int S,
-                       int Fm, const int* nearest_idx, float* stats, int ld_stats, void* stream) {
+                       int Fm, const int* nearest_idx, float* stats, int ld_stats, const float* aff_scale,
+                       const float* aff_shift, void* stream) {
   if (B <= 0) return 0;
   PA_REQUIRE(S >= 1 && S <= pa::POOL_MAXS && Tp >= 1 && Tp <= pa::POOLR_MAXT && ld_stats >= 2 * C,
              "pa_stats_pool_rows: S <= %d, 1 <= T' <= %d and ld_stats >= 2 C required (got %d, %d)",
              pa::POOL_MAXS, pa::POOLR_MAXT, S, Tp);
   pa::ProfScope prof("k_stats_pool_rows", stream, 6.0 * B * S * C * Tp, 4.0 * B * C * Tp + 8.0 * B * S * C);
   hipLaunchKernelGGL(pa::k_stats_pool_rows, dim3(pa::cdiv(C, 256), B), dim3(256), 0, (hipStream_t)stream, feat,
-                     T0, Tp, C, ld, masks, S, Fm, nearest_idx, stats, ld_stats);
+                     T0, Tp, C, ld, masks, S, Fm, nearest_idx, stats, ld_stats, aff_scale, aff_shift);
   PA_CHECK_LAUNCH("pa_stats_pool_rows");
   return 0;
 }

@@ -6,8 +6,8 @@
 //      activation matrix shifted by 16 j d rows: a layer is k chained GEMMs C += A(shift j) W_j^T on
 //      pa_gemm_tn_ex (bias with the first, LeakyReLU with the last); rows whose taps run past the end of
 //      their chunk hold garbage and are never read (valid frames shrink 589 -> 585 -> 581 -> 575).
-//      Each BatchNorm (eval: an affine map) is folded on the host into the NEXT layer's weights / bias and,
-//      for the last one, into the embedding Linear (mean -> s mean + t, std -> |s| std).
+//      Each BatchNorm (eval: an affine map) is folded on the host into the NEXT layer's weights / bias; the
+//      last one is applied on load inside the pooling kernel (an all-zero mask must pool to 0, not to its shift).
 //   -> weighted statistics pooling over the valid frames for all masks of a chunk (k_stats_pool_rows)
 //   -> Linear(3000 -> dimension).
 #include <hip/hip_runtime.h>
@@ -147,7 +147,7 @@ int pa_xvec_forward(const pa_xvec_weights* w, const float* wav, int64_t wav_len,
   // statistics pooling over the Tp valid frames, for every mask of a chunk at once
   const int S = masks ? num_masks : 1;
   RUN(pa_stats_pool_rows(in, B, p.T, p.Tp, cin, cin, masks, S, mask_frames, nearest_idx, ws + p.stats,
-                         p.ldstats, stream));
+                         p.ldstats, w->bn_scale, w->bn_shift, stream));
   // embedding Linear(2 C -> dimension) (xvector.py:250, 348); K padded to a multiple of 32 with zeros
   RUN(pa_gemm_tn_ex(ws + p.stats, p.ldstats, w->emb_w, p.ldstats, w->emb_b, nullptr, emb, w->dimension, B * S,
                     w->dimension, p.ldstats, 0, 0, stream));

@@ -64,7 +64,7 @@ class XvecWeights(C.Structure):
         ("sinc_filt", c_fp), ("norm0", c_fp), ("conv1_w", c_fp), ("conv1_b", c_fp), ("norm1", c_fp),
         ("conv2_w", c_fp), ("conv2_b", c_fp), ("norm2", c_fp),
         ("tdnn_w", c_fp * PA_XVEC_TDNN), ("tdnn_b", c_fp * PA_XVEC_TDNN),
-        ("emb_w", c_fp), ("emb_b", c_fp),
+        ("bn_scale", c_fp), ("bn_shift", c_fp), ("emb_w", c_fp), ("emb_b", c_fp),
     ]
 
 
@@ -163,7 +163,7 @@ _OPTIONAL: list[tuple] = [
     ("pa_stats_pool", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp,
                        c_fp], C.c_int),
     ("pa_stats_pool_rows", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp,
-                            c_fp, C.c_int, c_fp], C.c_int),
+                            c_fp, C.c_int, c_fp, c_fp, c_fp], C.c_int),
     ("pa_xvec_num_frames", [C.POINTER(XvecWeights), C.c_int], C.c_int),
     ("pa_xvec_workspace_bytes", [C.POINTER(XvecWeights), C.c_int, C.c_int, C.c_int], C.c_size_t),
     ("pa_xvec_forward", [C.POINTER(XvecWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int, c_fp,

@@ -183,8 +183,9 @@ class XVectorPack:
     (models/embedding/xvector.py:205-252).  State-dict layout: sincnet.*, tdnns.{3l}.{weight,bias} (Conv1d),
     tdnns.{3l+2}.{weight,bias,running_mean,running_var} (BatchNorm1d, eval), embedding.{weight,bias}.
     Every BatchNorm follows a LeakyReLU, so it cannot be folded backwards; being an affine map it is folded
-    FORWARD, in float64: into the next convolution (W_j diag(s), b + sum_j W_j t) and, for the last one,
-    through the statistics pooling (mean -> s mean + t, std -> |s| std) into the embedding Linear."""
+    FORWARD, in float64, into the next convolution (W_j diag(s), b + sum_j W_j t); the last one is handed to
+    the pooling kernel, which applies it on load (it cannot move past the pooling: an all-zero mask pools
+    to mean = std = 0, not to the BatchNorm's shift)."""
 
     KERNEL, DILATION = (5, 3, 3, 1, 1), (1, 2, 3, 1, 1)
 
@@ -220,13 +221,13 @@ class XVectorPack:
         ew, eb = sd["embedding.weight"].double(), sd["embedding.bias"].double()
         C_ = int(w.tdnn_channels[ffi.PA_XVEC_TDNN - 1])
         assert ew.shape[1] == 2 * C_
-        eb = eb + ew[:, :C_] @ shift
         ld = (2 * C_ + 31) // 32 * 32
         packed = torch.zeros(ew.shape[0], ld, dtype=torch.float64)
-        packed[:, :C_] = ew[:, :C_] * scale
-        packed[:, C_:2 * C_] = ew[:, C_:] * scale.abs()
+        packed[:, :2 * C_] = ew
+        w.bn_scale, w.bn_shift = self._up(scale.float()), self._up(shift.float())
+        self.last_batchnorm = (self._keep[-2], self._keep[-1])
         w.emb_w, w.emb_b = self._up(packed.float()), self._up(eb.float())
-        self.folded_embedding = (self._keep[-2], self._keep[-1])
+        self.embedding = (self._keep[-2], self._keep[-1])
         w.dimension = int(ew.shape[0])
         self.struct = w
 

@@ -242,8 +242,9 @@ def test_optimal_mapping_onto_reference_speakers():
 
 def test_xvector_pack_folds_batchnorm_forward():
     """XVectorPack (weights.py): every BatchNorm1d of the TDNN stack follows a LeakyReLU, so it is folded into
-    the NEXT convolution and, for the last one, through the statistics pooling into the embedding Linear.
-    The folded chain, evaluated with plain torch ops, equals the oracle module (xvector.py:330-349)."""
+    the NEXT convolution; the last one stays an affine map in front of the statistics pooling (an all-zero
+    mask pools to 0, not to its shift).  The folded chain, evaluated with plain torch ops, equals the oracle
+    module (xvector.py:330-349), also for an all-zero mask."""
     import torch.nn.functional as F
     from oracle import seeded_xvector
     from pyannote_audio_amd.weights import XVectorPack
@@ -252,6 +253,7 @@ def test_xvector_pack_folds_batchnorm_forward():
     g = torch.Generator().manual_seed(0)
     wav = (0.1 * torch.randn(2, 1, 32000, generator=g)).clamp(-1, 1)
     w = (torch.rand(2, 117, generator=g) < 0.6).float()
+    w[1] = 0.0
     with torch.inference_mode():
         want = model(wav, weights=w)
         x = model.sincnet(wav)                                        # (B, 60, T)
@@ -259,8 +261,9 @@ def test_xvector_pack_folds_batchnorm_forward():
         for (taps, bias), d in zip(pack.folded_tdnn, XVectorPack.DILATION):
             k, cout, cin = taps.shape
             x = F.leaky_relu(F.conv1d(x, taps.permute(1, 2, 0).contiguous(), bias, dilation=d))
-        stats = model.stats_pool(x, weights=w)                        # mean | std of the UN-normalised output
-        ew, eb = pack.folded_embedding
+        sc, sh = pack.last_batchnorm
+        stats = model.stats_pool(x * sc.view(1, -1, 1) + sh.view(1, -1, 1), weights=w)
+        ew, eb = pack.embedding
         got = stats @ ew[:, :stats.shape[1]].T + eb
     assert ew.shape[1] == 3008 and torch.count_nonzero(ew[:, 3000:]) == 0
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
