@@ -182,6 +182,82 @@ int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* 
                   const int* nearest_idx, float* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * SSeRiouSS segmentation model: replaces SSeRiouSS.forward (models/segmentation/SSeRiouSS.py:289-328) =
+ * torchaudio wav2vec 2.0 / WavLM `extract_features` -> (softmax-weighted mix of | one of) the transformer
+ * layer outputs -> bi-LSTM stack -> Linear head -> classifier, as called from Inference.infer.
+ * Weight layouts (all [out][in] row-major like torch unless stated):
+ * ---------------------------------------------------------------------------------------- */
+#define PA_W2V_MAX_CONV 8
+#define PA_W2V_MAX_LAYERS 24
+typedef struct pa_w2v_layer {
+  const float* qk_w;   /* [2D][D] q rows then k rows (in_proj_weight[:2D] / q_proj, k_proj) */
+  const float* qk_b;   /* [2D] */
+  const float* v_w;    /* [D][D]; its bias is folded into out_b (soft-max rows sum to 1) */
+  const float* out_w;  /* [D][D] */
+  const float* out_b;  /* [D] = out_proj.bias + out_proj.weight @ v_bias */
+  const float* ln1_g;  /* layer_norm */
+  const float* ln1_b;
+  const float* ff1_w;  /* [F][D] feed_forward.intermediate_dense */
+  const float* ff1_b;
+  const float* ff2_w;  /* [D][F] feed_forward.output_dense */
+  const float* ff2_b;
+  const float* ln2_g;  /* final_layer_norm */
+  const float* ln2_b;
+  const float* gate_w;     /* WavLM only: gru_rel_pos_linear [8][D/H] */
+  const float* gate_b;     /* [8] */
+  const float* gate_const; /* gru_rel_pos_const [H] */
+} pa_w2v_layer;
+
+typedef struct pa_sser_weights {
+  int32_t num_conv;                        /* feature extractor layers (7) */
+  int32_t conv_channels[PA_W2V_MAX_CONV];  /* multiples of 32 */
+  int32_t conv_kernel[PA_W2V_MAX_CONV];    /* 10, 3, 3, 3, 3, 2, 2 (first <= 16) */
+  int32_t conv_stride[PA_W2V_MAX_CONV];    /* 5, 2, 2, 2, 2, 2, 2 */
+  int32_t extractor_layer_norm;            /* 0: "group_norm" (GroupNorm on layer 0 only), 1: "layer_norm" */
+  int32_t embed_dim, num_layers, num_heads, ff_dim, layer_norm_first;
+  int32_t pos_kernel, pos_groups;          /* 128, 16 */
+  int32_t wavlm;                           /* gated relative position bias (rel_bias argument of the call) */
+  int32_t use_layer;                       /* wav2vec_layer: < 0 = weighted mix of all layers */
+  int32_t lstm_layers, lstm_hidden, lstm_bidir, num_linear, linear_hidden, num_classes, num_speakers;
+  const float* conv_w[PA_W2V_MAX_CONV];      /* layer 0: [C0][K0]; layer l: [C_l][k * C_{l-1}], index j * C + c */
+  const float* conv_b[PA_W2V_MAX_CONV];      /* or NULL (extractor_conv_bias = False) */
+  const float* conv_norm_g[PA_W2V_MAX_CONV]; /* GroupNorm (layer 0) / LayerNorm (every layer) affine */
+  const float* conv_norm_b[PA_W2V_MAX_CONV];
+  const float* proj_ln_g; /* encoder.feature_projection.layer_norm */
+  const float* proj_ln_b;
+  const float* proj_w;    /* [D][C_last] */
+  const float* proj_b;
+  const float* pos_w;     /* [groups][kernel][D/groups (in)][D/groups (out)], weight_norm materialised */
+  const float* pos_b;     /* [D] */
+  const float* enc_ln_g;  /* encoder.transformer.layer_norm (applied up front when layer_norm_first) */
+  const float* enc_ln_b;
+  pa_w2v_layer layers[PA_W2V_MAX_LAYERS];
+  float layer_mix[PA_W2V_MAX_LAYERS];      /* softmax(wav2vec_weights) */
+  const float* lstm_wih[PA_MAX_LSTM_LAYERS]; /* as in pa_seg_weights (layer 0: Kin = embed_dim) */
+  const float* lstm_bias[PA_MAX_LSTM_LAYERS];
+  const float* lstm_whh[PA_MAX_LSTM_LAYERS];
+  const float* lin_w[PA_MAX_LINEAR];
+  const float* lin_b[PA_MAX_LINEAR];
+  const float* cls_w;
+  const float* cls_b;
+  const uint8_t* powerset_map;             /* NULL = multi-label head (sigmoid scores) */
+} pa_sser_weights;
+
+/* frames per chunk (SSeRiouSS.num_frames, SSeRiouSS.py:217-241); 0 = too short */
+int pa_sser_num_frames(const pa_sser_weights* w, int num_samples);
+size_t pa_sser_workspace_bytes(const pa_sser_weights* w, int num_chunks, int num_samples);
+/* chunks and outputs as pa_seg_forward; rel_bias: [H][T][T] fp32 = rel_attn_embed[bucket(k - q)] for the
+ * T = pa_sser_num_frames(num_samples) frames of a chunk (WavLM), NULL for a wav2vec 2.0 encoder */
+int pa_sser_forward(const pa_sser_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                    int num_chunks, int num_samples, const float* rel_bias, float* logp, uint8_t* multilabel,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* outer x inner independent TN GEMMs in one launch (operand z = (zo, zi) starts zo * s?o + zi * s?i floats
+ * after its base pointer); act 0 or 3 (GELU) */
+int pa_gemm_tn_batched(const float* A, int lda, long sAo, long sAi, const float* W, int ldw, long sWo, long sWi,
+                       const float* bias, float* C, long ldc, long sCo, long sCi, int M, int N, int K,
+                       int outer, int inner, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * XVectorSincNet embedding model: replaces XVectorSincNet.forward (models/embedding/xvector.py:330-349) =
  * SincNet -> 5 x (Conv1d(k, dilation) + LeakyReLU + BatchNorm1d) -> StatsPool(weights) -> Linear, as called
  * by PyannoteAudioPretrainedSpeakerEmbedding (pipelines/speaker_verification.py:704-716).

@@ -40,4 +40,6 @@ from .models import (  # noqa: F401
     seeded_wespeaker,
     XVectorSincNet,
     seeded_xvector,
+    SSeRiouSS,
+    seeded_sseriouss,
 )

@@ -452,6 +452,94 @@ class WeSpeakerResNet34(nn.Module):
         return self.resnet(self.compute_fbank(waveforms), weights=weights)
 
 
+class SSeRiouSS(nn.Module):
+    """wav2vec > LSTM > feed-forward > classifier (models/segmentation/SSeRiouSS.py:42-328; pinned bit for bit
+    to that class -- both on oracle/wav2vec2.py, the unpinned restatement of torchaudio's encoder -- by
+    tests/test_reference_pipeline.py).  `wav2vec`: a bundle name ("WAVLM_BASE") or the keyword arguments of
+    torchaudio.models.wav2vec2_model."""
+
+    def __init__(self, num_classes: int = 7, wav2vec="WAVLM_BASE", wav2vec_layer: int = -1,
+                 lstm: Optional[dict] = None, linear: Optional[dict] = None, powerset: bool = True):
+        super().__init__()
+        from . import wav2vec2 as w2v
+        self.powerset = powerset
+        self.wav2vec_layer = wav2vec_layer
+        if isinstance(wav2vec, str):
+            bundle = w2v.PIPELINES[wav2vec]
+            dim, layers = bundle._params["encoder_embed_dim"], bundle._params["encoder_num_layers"]
+            self.wav2vec = bundle.get_model()
+        else:
+            self.wav2vec = w2v.wav2vec2_model(**wav2vec)
+            dim, layers = wav2vec["encoder_embed_dim"], wav2vec["encoder_num_layers"]
+        if wav2vec_layer < 0:
+            self.wav2vec_weights = nn.Parameter(torch.ones(layers))
+        self.hp_lstm = {"hidden_size": 128, "num_layers": 4, "bidirectional": True, "monolithic": True,
+                        "dropout": 0.0, **(lstm or {})}
+        self.hp_linear = {"hidden_size": 128, "num_layers": 2, **(linear or {})}
+        H, L, bi = self.hp_lstm["hidden_size"], self.hp_lstm["num_layers"], self.hp_lstm["bidirectional"]
+        if self.hp_lstm["monolithic"]:
+            self.lstm = nn.LSTM(dim, hidden_size=H, num_layers=L, bidirectional=bi, batch_first=True,
+                                dropout=self.hp_lstm["dropout"])
+        else:
+            self.lstm = nn.ModuleList([nn.LSTM(dim if i == 0 else H * (2 if bi else 1), hidden_size=H,
+                                               num_layers=1, bidirectional=bi, batch_first=True)
+                                       for i in range(L)])
+        dims = [H * (2 if bi else 1)] + [self.hp_linear["hidden_size"]] * self.hp_linear["num_layers"]
+        if self.hp_linear["num_layers"] > 0:
+            self.linear = nn.ModuleList([nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
+        self.classifier = nn.Linear(dims[-1], num_classes)
+        self.activation = nn.LogSoftmax(dim=-1) if powerset else nn.Sigmoid()
+
+    def forward(self, waveforms):
+        num_layers = None if self.wav2vec_layer < 0 else self.wav2vec_layer
+        outputs, _ = self.wav2vec.extract_features(waveforms.squeeze(1), num_layers=num_layers)
+        if num_layers is None:
+            outputs = torch.stack(outputs, dim=-1) @ F.softmax(self.wav2vec_weights, dim=0)
+        else:
+            outputs = outputs[-1]
+        if self.hp_lstm["monolithic"]:
+            outputs, _ = self.lstm(outputs)
+        else:
+            for lstm in self.lstm:
+                outputs, _ = lstm(outputs)
+        if self.hp_linear["num_layers"] > 0:
+            for linear in self.linear:
+                outputs = F.leaky_relu(linear(outputs))
+        return self.activation(self.classifier(outputs))
+
+
+#: a small wav2vec 2.0 configuration for tests (layer_norm extractor, pre-LN encoder: the "large" recipe)
+TINY_WAV2VEC2 = dict(
+    extractor_mode="layer_norm", extractor_conv_layer_config=[(64, 10, 5), (64, 3, 2), (64, 3, 2), (64, 2, 2)],
+    extractor_conv_bias=True, encoder_embed_dim=128, encoder_projection_dropout=0.0, encoder_pos_conv_kernel=32,
+    encoder_pos_conv_groups=4, encoder_num_layers=3, encoder_num_heads=4, encoder_attention_dropout=0.0,
+    encoder_ff_interm_features=256, encoder_ff_interm_dropout=0.0, encoder_dropout=0.0,
+    encoder_layer_norm_first=True, encoder_layer_drop=0.0, aux_num_out=None)
+
+
+def seeded_sseriouss(seed: int = 1357, wav2vec="WAVLM_BASE", num_layers: int = 2, wav2vec_layer: int = -1,
+                     classifier_gain: float = 8.0) -> SSeRiouSS:
+    """Default-initialised SSeRiouSS; norms, layer weights, the gate constants and the relative position
+    table are perturbed so that every parameter takes part."""
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    model = SSeRiouSS(wav2vec=wav2vec, lstm={"num_layers": num_layers}, wav2vec_layer=wav2vec_layer)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (nn.LayerNorm, nn.GroupNorm)):
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+        for name, p in model.named_parameters():
+            if name.endswith("gru_rel_pos_const"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            if name.endswith("in_proj_bias") or name.endswith("out_proj.bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+        if wav2vec_layer < 0:
+            model.wav2vec_weights.copy_(torch.randn(model.wav2vec_weights.shape, generator=g))
+        model.classifier.weight.mul_(classifier_gain)
+    return model.eval()
+
+
 class XVectorSincNet(nn.Module):
     """SincNet -> 5 x (Conv1d + LeakyReLU + BatchNorm1d) -> StatsPool -> Linear
     (models/embedding/xvector.py:205-349; pinned bit for bit to that class by

@@ -48,8 +48,13 @@ class SW:
 
 
 def receptive_field(model, sample_rate: int = 16000) -> SW:
-    """core/model.py:168-184 for SincNet kernels [251,3,5,3,5,3] / strides [10,3,1,3,1,3]."""
-    ks, ss = [251, 3, 5, 3, 5, 3], [model.sincnet.stride, 3, 1, 3, 1, 3]
+    """core/model.py:168-184 for SincNet kernels [251,3,5,3,5,3] / strides [10,3,1,3,1,3] (PyanNet), or the
+    wav2vec feature extractor's convolutions (SSeRiouSS.py:217-287)."""
+    if hasattr(model, "wav2vec"):
+        layers = model.wav2vec.feature_extractor.conv_layers
+        ks, ss = [l.kernel_size for l in layers], [l.stride for l in layers]
+    else:
+        ks, ss = [251, 3, 5, 3, 5, 3], [model.sincnet.stride, 3, 1, 3, 1, 3]
 
     def size(n):
         for k, s in reversed(list(zip(ks, ss))):

@@ -1,0 +1,300 @@
+"""Oracle (CPU) restatement of torchaudio's wav2vec 2.0 / WavLM encoder -- TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: torchaudio 2.10.0 (`torchaudio.models.wav2vec2_model`, `wavlm_model`,
+`torchaudio.pipelines.WAVLM_BASE`) is a third-party dependency of the reference
+(models/segmentation/SSeRiouSS.py:29, 100-124) that is neither vendored under /root/reference nor installed
+here, and there is no network.  What follows restates its PUBLISHED architecture (Baevski et al. 2020,
+"wav2vec 2.0"; Chen et al. 2022, "WavLM", section 3.1 + the gated relative position bias of eq. 3-5) with
+torchaudio's module / parameter names (components.py, wavlm_attention.py), so that a real checkpoint's
+state dict would load; a deviation of torchaudio's code from this restatement would go unnoticed.
+The reference's OWN file (SSeRiouSS.py: layer weighting, LSTM, head) is executed for real on top of this
+module by tests/test_reference_pipeline.py.
+
+    Wav2Vec2Model.extract_features(waveforms (B, n), num_layers=None) -> ([(B, T, D)] * L, None)
+      feature_extractor   7 x (Conv1d, [GroupNorm on layer 0 | LayerNorm on every layer], GELU)
+      encoder.feature_projection   LayerNorm(512) -> Linear(512, D)
+      encoder.transformer          x + GELU(grouped Conv1d(k=128, groups=16, weight_norm)), then L layers of
+                                   self-attention (+ WavLM's gated relative position bias) and a GELU MLP,
+                                   post-LN (base) or pre-LN (large)
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BASE_CONV = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
+
+#: constructor arguments of torchaudio.models.wavlm_base() / the WAVLM_BASE(_PLUS) bundles
+WAVLM_BASE = dict(
+    extractor_mode="group_norm", extractor_conv_layer_config=BASE_CONV, extractor_conv_bias=False,
+    encoder_embed_dim=768, encoder_projection_dropout=0.1, encoder_pos_conv_kernel=128,
+    encoder_pos_conv_groups=16, encoder_num_layers=12, encoder_num_heads=12, encoder_num_buckets=320,
+    encoder_max_distance=800, encoder_attention_dropout=0.1, encoder_ff_interm_features=3072,
+    encoder_ff_interm_dropout=0.0, encoder_dropout=0.1, encoder_layer_norm_first=False,
+    encoder_layer_drop=0.05, aux_num_out=None)
+
+
+class ChannelLayerNorm(nn.LayerNorm):
+    """LayerNorm over the channels of a (B, C, T) tensor (components.LayerNorm)"""
+
+    def forward(self, x):
+        return F.layer_norm(x.transpose(-2, -1), self.normalized_shape, self.weight, self.bias,
+                            self.eps).transpose(-2, -1)
+
+
+class ConvLayerBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias, layer_norm):
+        super().__init__()
+        self.kernel_size, self.stride = kernel_size, stride
+        self.layer_norm = layer_norm
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, bias=bias)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.layer_norm is not None:
+            x = self.layer_norm(x)
+        return F.gelu(x)
+
+
+class FeatureExtractor(nn.Module):
+    def __init__(self, mode: str, shapes, bias: bool):
+        super().__init__()
+        blocks, cin = [], 1
+        for i, (cout, k, s) in enumerate(shapes):
+            norm = None
+            if mode == "group_norm" and i == 0:
+                norm = nn.GroupNorm(num_groups=cout, num_channels=cout, affine=True)
+            elif mode == "layer_norm":
+                norm = ChannelLayerNorm(cout, elementwise_affine=True)
+            blocks.append(ConvLayerBlock(cin, cout, k, s, bias, norm))
+            cin = cout
+        self.conv_layers = nn.ModuleList(blocks)
+
+    def forward(self, x):                      # (B, n) -> (B, T, C)
+        x = x.unsqueeze(1)
+        for layer in self.conv_layers:
+            x = layer(x)
+        return x.transpose(1, 2)
+
+
+class FeatureProjection(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(in_features)
+        self.projection = nn.Linear(in_features, out_features)
+
+    def forward(self, x):
+        return self.projection(self.layer_norm(x))
+
+
+class ConvolutionalPositionalEmbedding(nn.Module):
+    def __init__(self, embed_dim, kernel_size, groups):
+        super().__init__()
+        conv = nn.Conv1d(embed_dim, embed_dim, kernel_size, padding=kernel_size // 2, groups=groups)
+        self.conv = nn.utils.parametrizations.weight_norm(conv, name="weight", dim=2)
+        self.num_remove = 1 if kernel_size % 2 == 0 else 0
+
+    def forward(self, x):                      # (B, T, C)
+        x = self.conv(x.transpose(-2, -1))
+        if self.num_remove > 0:
+            x = x[..., :-self.num_remove]
+        return F.gelu(x).transpose(-2, -1)
+
+
+class SelfAttention(nn.Module):
+    """wav2vec 2.0: scaled dot-product attention with separate q/k/v/out projections"""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, embed_dim // num_heads
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, x, position_bias=None):
+        B, T, E = x.shape
+        shape = (B, T, self.num_heads, self.head_dim)
+        q = self.q_proj(x).view(shape).transpose(2, 1)
+        k = self.k_proj(x).view(shape).transpose(2, 1)
+        v = self.v_proj(x).view(shape).transpose(2, 1)
+        out = F.scaled_dot_product_attention(q, k, v)
+        return self.out_proj(out.transpose(1, 2).reshape(B, T, E)), None
+
+
+class WavLMSelfAttention(nn.Module):
+    """WavLM: the same attention with a bucketed relative position bias (T5-style buckets, embedded in the
+    FIRST layer only and shared by all layers) gated per (batch, head, query) by the layer's input."""
+
+    def __init__(self, embed_dim, num_heads, has_relative_attention_bias, num_buckets, max_distance):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, embed_dim // num_heads
+        self.num_buckets, self.max_distance = num_buckets, max_distance
+        self.attention = nn.MultiheadAttention(embed_dim, num_heads, bias=True, batch_first=True)
+        self.rel_attn_embed = nn.Embedding(num_buckets, num_heads) if has_relative_attention_bias else None
+        self.gru_rel_pos_linear = nn.Linear(self.head_dim, 8)
+        self.gru_rel_pos_const = nn.Parameter(torch.ones(1, num_heads, 1, 1))
+
+    def relative_position_bucket(self, relative_positions):
+        num_buckets = self.num_buckets // 2
+        buckets = (relative_positions > 0).to(torch.long) * num_buckets
+        rel = torch.abs(relative_positions)
+        max_exact = num_buckets // 2
+        is_small = rel < max_exact
+        large = max_exact + (torch.log(rel.float() / max_exact) / math.log(self.max_distance / max_exact)
+                             * (num_buckets - max_exact)).to(torch.long)
+        large = torch.min(large, torch.full_like(large, num_buckets - 1))
+        return buckets + torch.where(is_small, rel, large)
+
+    def compute_bias(self, query_length, key_length):
+        context = torch.arange(query_length, dtype=torch.long)[:, None]
+        memory = torch.arange(key_length, dtype=torch.long)[None, :]
+        bucket = self.relative_position_bucket(memory - context)
+        return self.rel_attn_embed(bucket).permute([2, 0, 1])            # (H, Tq, Tk)
+
+    def gate(self, x):
+        """(B, H, T, 1): gate_a * (gate_b * const - 1) + 2 from the layer input split into heads"""
+        B, T, _ = x.shape
+        q = x.view(B, T, self.num_heads, -1).permute(0, 2, 1, 3)
+        ga, gb = torch.sigmoid(self.gru_rel_pos_linear(q).view(B, self.num_heads, T, 2, 4).sum(-1)).chunk(2, dim=-1)
+        return ga * (gb * self.gru_rel_pos_const - 1.0) + 2.0
+
+    def forward(self, x, position_bias=None):
+        B, T, E = x.shape
+        if self.rel_attn_embed is not None and position_bias is None:
+            position_bias = self.compute_bias(T, T).unsqueeze(0).repeat(B, 1, 1, 1)
+        mask = None
+        if position_bias is not None:
+            mask = (self.gate(x).view(B, self.num_heads, -1, 1) * position_bias).view(B, self.num_heads, T, T)
+        qkv = F.linear(x, self.attention.in_proj_weight, self.attention.in_proj_bias)
+        q, k, v = qkv.chunk(3, -1)
+        shape = (B, T, self.num_heads, self.head_dim)
+        q, k, v = (t.view(shape).transpose(2, 1) for t in (q, k, v))
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        out = out.transpose(1, 2).reshape(B, T, E)
+        return self.attention.out_proj(out), position_bias
+
+
+class FeedForward(nn.Module):
+    def __init__(self, io_features, intermediate_features):
+        super().__init__()
+        self.intermediate_dense = nn.Linear(io_features, intermediate_features)
+        self.output_dense = nn.Linear(intermediate_features, io_features)
+
+    def forward(self, x):
+        return self.output_dense(F.gelu(self.intermediate_dense(x)))
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, attention, embed_dim, layer_norm_first, feed_forward):
+        super().__init__()
+        self.attention = attention
+        self.layer_norm = nn.LayerNorm(embed_dim)
+        self.layer_norm_first = layer_norm_first
+        self.feed_forward = feed_forward
+        self.final_layer_norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x, position_bias=None):
+        residual = x
+        if self.layer_norm_first:
+            x = self.layer_norm(x)
+        x, position_bias = self.attention(x, position_bias=position_bias)
+        x = residual + x
+        if self.layer_norm_first:
+            x = x + self.feed_forward(self.final_layer_norm(x))
+        else:
+            x = self.layer_norm(x)
+            x = self.final_layer_norm(x + self.feed_forward(x))
+        return x, position_bias
+
+
+class Transformer(nn.Module):
+    def __init__(self, pos_conv_embed, layers, embed_dim, layer_norm_first):
+        super().__init__()
+        self.pos_conv_embed = pos_conv_embed
+        self.layer_norm = nn.LayerNorm(embed_dim)
+        self.layer_norm_first = layer_norm_first
+        self.layers = layers
+
+    def get_intermediate_outputs(self, x, num_layers: Optional[int] = None) -> List[torch.Tensor]:
+        x = x + self.pos_conv_embed(x)
+        if self.layer_norm_first:
+            x = self.layer_norm(x)
+        ret, position_bias = [], None
+        for layer in self.layers:
+            x, position_bias = layer(x, position_bias=position_bias)
+            ret.append(x)
+            if num_layers is not None and len(ret) >= num_layers:
+                return ret
+        return ret
+
+
+class Encoder(nn.Module):
+    def __init__(self, feature_projection, transformer):
+        super().__init__()
+        self.feature_projection = feature_projection
+        self.transformer = transformer
+
+    def extract_features(self, features, num_layers=None):
+        return self.transformer.get_intermediate_outputs(self.feature_projection(features), num_layers)
+
+
+class Wav2Vec2Model(nn.Module):
+    def __init__(self, feature_extractor, encoder):
+        super().__init__()
+        self.feature_extractor = feature_extractor
+        self.encoder = encoder
+
+    def extract_features(self, waveforms, lengths=None, num_layers: Optional[int] = None
+                         ) -> Tuple[List[torch.Tensor], None]:
+        return self.encoder.extract_features(self.feature_extractor(waveforms), num_layers), None
+
+
+def _model(wavlm: bool, extractor_mode, extractor_conv_layer_config, extractor_conv_bias, encoder_embed_dim,
+           encoder_pos_conv_kernel, encoder_pos_conv_groups, encoder_num_layers, encoder_num_heads,
+           encoder_ff_interm_features, encoder_layer_norm_first, encoder_num_buckets=None,
+           encoder_max_distance=None, **_dropouts_and_aux) -> Wav2Vec2Model:
+    shapes = extractor_conv_layer_config or BASE_CONV
+    fe = FeatureExtractor(extractor_mode, shapes, extractor_conv_bias)
+    layers = nn.ModuleList()
+    for i in range(encoder_num_layers):
+        if wavlm:
+            att = WavLMSelfAttention(encoder_embed_dim, encoder_num_heads, has_relative_attention_bias=(i == 0),
+                                     num_buckets=encoder_num_buckets, max_distance=encoder_max_distance)
+        else:
+            att = SelfAttention(encoder_embed_dim, encoder_num_heads)
+        layers.append(EncoderLayer(att, encoder_embed_dim, encoder_layer_norm_first,
+                                   FeedForward(encoder_embed_dim, encoder_ff_interm_features)))
+    transformer = Transformer(ConvolutionalPositionalEmbedding(encoder_embed_dim, encoder_pos_conv_kernel,
+                                                               encoder_pos_conv_groups),
+                              layers, encoder_embed_dim, encoder_layer_norm_first)
+    return Wav2Vec2Model(fe, Encoder(FeatureProjection(shapes[-1][0], encoder_embed_dim), transformer))
+
+
+def wav2vec2_model(**config) -> Wav2Vec2Model:
+    """torchaudio.models.wav2vec2_model(**config) (what SSeRiouSS builds from a dict, SSeRiouSS.py:120-123)"""
+    return _model(False, **config)
+
+
+def wavlm_model(**config) -> Wav2Vec2Model:
+    """torchaudio.models.wavlm_model(**config)"""
+    return _model(True, **config)
+
+
+class _Bundle:
+    """torchaudio.pipelines.WAVLM_BASE / WAVLM_BASE_PLUS as far as SSeRiouSS.py:100-109 uses them
+    (`get_model()` here returns RANDOMLY INITIALISED weights: the pretrained ones need the network)."""
+    _sample_rate = 16000
+
+    def __init__(self, params, wavlm=True):
+        self._params, self._wavlm = params, wavlm
+
+    def get_model(self):
+        return (wavlm_model if self._wavlm else wav2vec2_model)(**self._params)
+
+
+PIPELINES = {"WAVLM_BASE": _Bundle(WAVLM_BASE), "WAVLM_BASE_PLUS": _Bundle(WAVLM_BASE)}

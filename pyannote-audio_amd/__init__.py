@@ -7,7 +7,7 @@ __version__ = "0.1.0"
 
 from .core import Annotation, Segment, SlidingWindow, SlidingWindowFeature  # noqa: E402,F401
 from .audio import Audio  # noqa: E402,F401
-from .model import (Model, PyanNet, WeSpeakerResNet34, WeSpeakerResNet152, WeSpeakerResNet221,  # noqa: E402,F401
+from .model import (Model, PyanNet, SSeRiouSS, WeSpeakerResNet34, WeSpeakerResNet152, WeSpeakerResNet221,  # noqa: E402,F401
                     WeSpeakerResNet293, XVectorSincNet, Specifications, Problem, Resolution)  # noqa: E402,F401
 from .pipeline import Pipeline  # noqa: E402,F401
 from .inference import Inference  # noqa: E402,F401

@@ -78,6 +78,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 __device__ __forceinline__ float leaky_relu(float x) { return x > 0.f ? x : 0.01f * x; }
+// torch.nn.functional.gelu (approximate="none"): x * Phi(x) with the exact error function
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -26,15 +26,25 @@ constexpr int GK = 32;       // BK
 constexpr int GLD = GK + 4;  // LDS row stride (floats): 9 x 16-B slots -> conflict-free b128 reads
 
 // out_mode 0: C[m*ldc + n]; out_mode 1 (LSTM gate pre-activations): C[((m>>4)*N + n)*16 + (m&15)]
-// ACT: 0 none, 1 leaky_relu(0.01), 2 relu.  RES (out_mode 0 only): C = act(A W^T + bias + Res), Res laid
-// out like C -- the 1x1 "conv3 + bn3 + shortcut + relu" of a Bottleneck block (resnet.py:205-211).
+// ACT: 0 none, 1 leaky_relu(0.01), 2 relu, 3 gelu (erf).  RES (out_mode 0 only): C = act(A W^T + bias + Res),
+// Res laid out like C -- the 1x1 "conv3 + bn3 + shortcut + relu" of a Bottleneck block (resnet.py:205-211).
+// blockIdx.y = batch index z (the attention GEMMs of the wav2vec encoder): operand z starts
+// (z / inner) * s?o + (z % inner) * s?i floats after the base pointer (all zero for plain launches).
 template <int ACT, int OUT_MODE>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda,
                                                   const float* __restrict__ W, int ldw,
                                                   const float* __restrict__ bias,
                                                   const float* __restrict__ Res,
                                                   float* __restrict__ C, long ldc, int M, int N, int K,
-                                                  int nm, int nn) {
+                                                  int nm, int nn, int inner, long sAo, long sAi, long sWo,
+                                                  long sWi, long sCo, long sCi) {
+  if (gridDim.y > 1) {
+    const int zo = blockIdx.y / inner, zi = blockIdx.y % inner;
+    A += zo * sAo + zi * sAi;
+    W += zo * sWo + zi * sWi;
+    C += zo * sCo + zi * sCi;
+    if (Res != nullptr) Res += zo * sCo + zi * sCi;
+  }
   __shared__ __attribute__((aligned(16))) float As[GB * GLD];
   __shared__ __attribute__((aligned(16))) float Ws[GB * GLD];
   // block -> tile mapping; with 8 column tiles the 8 blocks sharing an A panel run on one XCD
@@ -123,6 +133,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
           if (OUT_MODE == 0 && Res != nullptr && n < N && m + e < M) v[e] += Res[(long)(m + e) * ldc + n];
           if (ACT == 1) v[e] = leaky_relu(v[e]);
           if (ACT == 2) v[e] = fmaxf(v[e], 0.f);
+          if (ACT == 3) v[e] = gelu_erf(v[e]);
         }
         if (n < N) {
           if (OUT_MODE == 0) {
@@ -319,6 +330,10 @@ int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bi
   return pa_gemm_tn_ex(A, lda, W, ldw, bias, nullptr, C, ldc, M, N, K, act, out_mode, stream);
 }
 
+int pa_gemm_tn_batched(const float* A, int lda, long sAo, long sAi, const float* W, int ldw, long sWo, long sWi,
+                       const float* bias, float* C, long ldc, long sCo, long sCi, int M, int N, int K,
+                       int outer, int inner, int act, void* stream);
+
 int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
                   float* C, long ldc, int M, int N, int K, int act, int out_mode, void* stream) {
   if (M <= 0 || N <= 0) return 0;
@@ -332,14 +347,41 @@ int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float*
   pa::ProfScope prof("k_gemm_tn", stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define PA_GEMM(ACT, OM)                                                                          \
   hipLaunchKernelGGL((pa::k_gemm_tn<ACT, OM>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, \
-                     Res, C, ldc, M, N, K, nm, nn)
+                     Res, C, ldc, M, N, K, nm, nn, 1, 0L, 0L, 0L, 0L, 0L, 0L)
   if (act == 0 && out_mode == 0) PA_GEMM(0, 0);
   else if (act == 1 && out_mode == 0) PA_GEMM(1, 0);
   else if (act == 2 && out_mode == 0) PA_GEMM(2, 0);
+  else if (act == 3 && out_mode == 0) PA_GEMM(3, 0);
   else if (act == 0 && out_mode == 1) PA_GEMM(0, 1);
   else PA_REQUIRE(false, "pa_gemm_tn: unsupported act/out_mode %d/%d", act, out_mode);
 #undef PA_GEMM
   PA_CHECK_LAUNCH("pa_gemm_tn");
+  return 0;
+}
+
+// outer x inner independent GEMMs in one launch: operand z = (zo, zi) starts zo * s?o + zi * s?i floats after
+// its base pointer (bias shared).  The per-(chunk, head) Q K^T and P V products of the wav2vec encoder.
+int pa_gemm_tn_batched(const float* A, int lda, long sAo, long sAi, const float* W, int ldw, long sWo, long sWi,
+                       const float* bias, float* C, long ldc, long sCo, long sCi, int M, int N, int K,
+                       int outer, int inner, int act, void* stream) {
+  if (M <= 0 || N <= 0 || outer <= 0 || inner <= 0) return 0;
+  PA_REQUIRE(K % pa::GK == 0 && lda % 4 == 0 && ldw % 4 == 0 && sAo % 4 == 0 && sAi % 4 == 0 && sWo % 4 == 0 &&
+                 sWi % 4 == 0,
+             "pa_gemm_tn_batched: K (%d) must be a multiple of 32 and every stride a multiple of 4", K);
+  PA_REQUIRE((long)outer * inner <= 65535, "pa_gemm_tn_batched: at most 65535 products per launch");
+  const int nm = pa::cdiv(M, pa::GB), nn = pa::cdiv(N, pa::GB);
+  const int grid = nn == 8 ? pa::cdiv(nm, 8) * 64 : nm * nn;
+  hipStream_t st = (hipStream_t)stream;
+  const double z = (double)outer * inner;
+  pa::ProfScope prof("k_gemm_tn", stream, 2.0 * z * M * N * K, 4.0 * z * ((double)M * K + (double)N * K + (double)M * N));
+#define PA_GEMMB(ACT)                                                                                          \
+  hipLaunchKernelGGL((pa::k_gemm_tn<ACT, 0>), dim3(grid, outer * inner), dim3(256), 0, st, A, lda, W, ldw, bias, \
+                     (const float*)nullptr, C, ldc, M, N, K, nm, nn, inner, sAo, sAi, sWo, sWi, sCo, sCi)
+  if (act == 0) PA_GEMMB(0);
+  else if (act == 3) PA_GEMMB(3);
+  else PA_REQUIRE(false, "pa_gemm_tn_batched: unsupported act %d", act);
+#undef PA_GEMMB
+  PA_CHECK_LAUNCH("pa_gemm_tn_batched");
   return 0;
 }
 

@@ -51,6 +51,39 @@ class EmbWeights(C.Structure):
     ]
 
 
+PA_W2V_MAX_CONV = 8
+PA_W2V_MAX_LAYERS = 24
+
+
+class W2vLayer(C.Structure):
+    """pa_w2v_layer (include/pyannote_amd.h)"""
+    _fields_ = [(n, c_fp) for n in ("qk_w", "qk_b", "v_w", "out_w", "out_b", "ln1_g", "ln1_b", "ff1_w", "ff1_b",
+                                    "ff2_w", "ff2_b", "ln2_g", "ln2_b", "gate_w", "gate_b", "gate_const")]
+
+
+class SserWeights(C.Structure):
+    """pa_sser_weights (include/pyannote_amd.h)"""
+    _fields_ = [
+        ("num_conv", C.c_int32), ("conv_channels", C.c_int32 * PA_W2V_MAX_CONV),
+        ("conv_kernel", C.c_int32 * PA_W2V_MAX_CONV), ("conv_stride", C.c_int32 * PA_W2V_MAX_CONV),
+        ("extractor_layer_norm", C.c_int32), ("embed_dim", C.c_int32), ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32), ("ff_dim", C.c_int32), ("layer_norm_first", C.c_int32),
+        ("pos_kernel", C.c_int32), ("pos_groups", C.c_int32), ("wavlm", C.c_int32), ("use_layer", C.c_int32),
+        ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_bidir", C.c_int32),
+        ("num_linear", C.c_int32), ("linear_hidden", C.c_int32), ("num_classes", C.c_int32),
+        ("num_speakers", C.c_int32),
+        ("conv_w", c_fp * PA_W2V_MAX_CONV), ("conv_b", c_fp * PA_W2V_MAX_CONV),
+        ("conv_norm_g", c_fp * PA_W2V_MAX_CONV), ("conv_norm_b", c_fp * PA_W2V_MAX_CONV),
+        ("proj_ln_g", c_fp), ("proj_ln_b", c_fp), ("proj_w", c_fp), ("proj_b", c_fp),
+        ("pos_w", c_fp), ("pos_b", c_fp), ("enc_ln_g", c_fp), ("enc_ln_b", c_fp),
+        ("layers", W2vLayer * PA_W2V_MAX_LAYERS), ("layer_mix", C.c_float * PA_W2V_MAX_LAYERS),
+        ("lstm_wih", c_fp * PA_MAX_LSTM_LAYERS), ("lstm_bias", c_fp * PA_MAX_LSTM_LAYERS),
+        ("lstm_whh", c_fp * PA_MAX_LSTM_LAYERS),
+        ("lin_w", c_fp * PA_MAX_LINEAR), ("lin_b", c_fp * PA_MAX_LINEAR),
+        ("cls_w", c_fp), ("cls_b", c_fp), ("powerset_map", c_fp),
+    ]
+
+
 PA_XVEC_TDNN = 5
 
 
@@ -164,6 +197,10 @@ _OPTIONAL: list[tuple] = [
                        c_fp], C.c_int),
     ("pa_stats_pool_rows", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp,
                             c_fp, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_sser_num_frames", [C.POINTER(SserWeights), C.c_int], C.c_int),
+    ("pa_sser_workspace_bytes", [C.POINTER(SserWeights), C.c_int, C.c_int], C.c_size_t),
+    ("pa_sser_forward", [C.POINTER(SserWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int, c_fp, c_fp, c_fp,
+                         c_fp, C.c_size_t, c_fp], C.c_int),
     ("pa_xvec_num_frames", [C.POINTER(XvecWeights), C.c_int], C.c_int),
     ("pa_xvec_workspace_bytes", [C.POINTER(XvecWeights), C.c_int, C.c_int, C.c_int], C.c_size_t),
     ("pa_xvec_forward", [C.POINTER(XvecWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int, c_fp,

@@ -307,12 +307,12 @@ class Model:
             checkpoint = p
         ckpt = load_checkpoint(checkpoint)
         arch = ckpt["pyannote.audio"]["architecture"]["class"]
-        klass = {"PyanNet": PyanNet, "WeSpeakerResNet34": WeSpeakerResNet34,
+        klass = {"PyanNet": PyanNet, "SSeRiouSS": SSeRiouSS, "WeSpeakerResNet34": WeSpeakerResNet34,
                  "WeSpeakerResNet152": WeSpeakerResNet152, "WeSpeakerResNet221": WeSpeakerResNet221,
                  "WeSpeakerResNet293": WeSpeakerResNet293, "XVectorSincNet": XVectorSincNet}.get(arch)
         if klass is None:
             raise NotImplementedError(
-                f"architecture {arch!r} is outside the accelerated hot path (PyanNet, "
+                f"architecture {arch!r} is outside the accelerated hot path (PyanNet, SSeRiouSS, "
                 "WeSpeakerResNet34/152/221/293, XVectorSincNet)")
         return klass(ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {})),
                      ckpt["pyannote.audio"]["specifications"])
@@ -364,6 +364,31 @@ class PyanNet(Model):
         return self.engine.forward(waveforms)
 
     forward = __call__
+
+
+class SSeRiouSS(PyanNet):
+    """models/segmentation/SSeRiouSS.py:42-328 (wav2vec 2.0 / WavLM > LSTM > feed-forward > classifier) over
+    the HIP wav2vec engine.  Frame geometry = the feature extractor's convolutions (:217-287)."""
+
+    ARCHITECTURE = ("pyannote.audio.models.segmentation.SSeRiouSS", "SSeRiouSS")
+
+    def _conv(self):
+        from .weights import wav2vec_config
+        shapes = wav2vec_config(self.hparams.get("wav2vec") or "WAVLM_BASE")["extractor_conv_layer_config"]
+        n = len(shapes)
+        return [k for _, k, _ in shapes], [s for _, _, s in shapes], [0] * n, [1] * n
+
+    def _build_engine(self, device):
+        from .segmentation import SSeRiouSSEngine
+        from .weights import SSeRiouSSPack
+        s = self.specifications
+        if s.powerset:
+            args = (s.num_powerset_classes, len(s.classes), s.powerset_max_classes)
+        elif s.problem in (Problem.MULTI_LABEL_CLASSIFICATION, Problem.BINARY_CLASSIFICATION):
+            args = (len(s.classes), len(s.classes), None)
+        else:
+            raise NotImplementedError(f"{s.problem} heads are outside the accelerated path")
+        return SSeRiouSSEngine(SSeRiouSSPack(self._state_dict, dict(self.hparams), *args, device))
 
 
 class WeSpeakerResNet34(Model):

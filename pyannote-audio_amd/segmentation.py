@@ -48,9 +48,9 @@ class SegmentationEngine:
         lib = ffi.load()
         w = self.pack.struct
         assert wav.dim() == 1 and wav.dtype == torch.float32
-        F = num_frames(num_samples)
+        F = self.frames_of(num_samples)
         if F <= 0:
-            raise ValueError(f"chunks of {num_samples} samples are too short for SincNet")
+            raise ValueError(f"chunks of {num_samples} samples are too short for this model")
         dev = self.pack.device
         if not self.pack.powerset:
             want_logp, want_multilabel = True, False
@@ -61,19 +61,29 @@ class SegmentationEngine:
         c0 = 0
         while c0 < num_chunks:
             nb = min(self.max_chunks, num_chunks - c0)
-            need = lib.pa_seg_workspace_bytes(w, nb, num_samples)
+            need = self._workspace_bytes(lib, w, nb, num_samples)
             ws = self._workspace(need)
             off = c0 * chunk_stride
             sub = wav[off:] if off < wav.numel() else wav[:0]
-            rc = lib.pa_seg_forward(
-                w, ffi.c_fp(sub.data_ptr()) if sub.numel() else ffi.c_fp(wav.data_ptr()),
+            rc = self._launch(
+                lib, w, ffi.c_fp(sub.data_ptr()) if sub.numel() else ffi.c_fp(wav.data_ptr()),
                 sub.numel(), chunk_stride, nb, num_samples,
                 ffi.ptr(logp[c0:c0 + nb]) if logp is not None else None,
-                ffi.ptr(ml[c0:c0 + nb]) if ml is not None else None,
-                ffi.ptr(ws), ws.numel(), ffi.stream())
-            ffi.check(rc, "pa_seg_forward")
+                ffi.ptr(ml[c0:c0 + nb]) if ml is not None else None, ws, F)
+            ffi.check(rc, "segmentation forward")
             c0 += nb
         return logp, ml
+
+    # -- model-specific entry points (PyanNet here; SSeRiouSSEngine overrides them)
+    def frames_of(self, num_samples: int) -> int:
+        return num_frames(num_samples)
+
+    def _workspace_bytes(self, lib, w, nb, num_samples):
+        return lib.pa_seg_workspace_bytes(w, nb, num_samples)
+
+    def _launch(self, lib, w, wav_ptr, wav_len, chunk_stride, nb, num_samples, logp_ptr, ml_ptr, ws, F):
+        return lib.pa_seg_forward(w, wav_ptr, wav_len, chunk_stride, nb, num_samples, logp_ptr, ml_ptr,
+                                  ffi.ptr(ws), ws.numel(), ffi.stream())
 
     def forward(self, waveforms: torch.Tensor) -> torch.Tensor:
         """(B, 1, N) -> (B, F, K) log-probabilities (the reference `Model.forward` contract)."""
@@ -82,3 +92,24 @@ class SegmentationEngine:
         x = waveforms.to(self.pack.device, torch.float32).contiguous().view(-1)
         logp, _ = self.forward_strided(x, N, B, N, want_logp=True, want_multilabel=False)
         return logp
+
+
+class SSeRiouSSEngine(SegmentationEngine):
+    """SSeRiouSS (models/segmentation/SSeRiouSS.py:289-328) over `pa_sser_forward`: wav2vec 2.0 / WavLM encoder
+    -> layer mix -> bi-LSTM stack -> head, on strided chunks of a device-resident waveform.  The feature
+    extractor's first stages are large (65 MB per 10 s chunk at 512 channels): 16 chunks per launch group."""
+
+    def __init__(self, pack, max_chunks: int = 16):
+        super().__init__(pack, max_chunks=max_chunks)
+
+    def frames_of(self, num_samples: int) -> int:
+        return ffi.load().pa_sser_num_frames(self.pack.struct, num_samples)
+
+    def _workspace_bytes(self, lib, w, nb, num_samples):
+        return lib.pa_sser_workspace_bytes(w, nb, num_samples)
+
+    def _launch(self, lib, w, wav_ptr, wav_len, chunk_stride, nb, num_samples, logp_ptr, ml_ptr, ws, F):
+        bias = self.pack.relative_bias(F)
+        return lib.pa_sser_forward(w, wav_ptr, wav_len, chunk_stride, nb, num_samples,
+                                   ffi.ptr(bias) if bias is not None else None, logp_ptr, ml_ptr,
+                                   ffi.ptr(ws), ws.numel(), ffi.stream())

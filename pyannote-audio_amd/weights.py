@@ -10,6 +10,7 @@ State-dict layout accepted (core/model.py:244-262):
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Optional
 
@@ -117,28 +118,7 @@ class SegmentationPack:
         w.num_classes, w.num_speakers = num_classes, num_speakers
         self.sinc_taps = pack_sincnet(sd, w, self._up)  # (80, 251) kept for tests
 
-        perm = _lstm_row_perm()
-        for l in range(L):
-            if lstm["monolithic"]:
-                key = lambda name, rev: f"lstm.{name}_l{l}" + ("_reverse" if rev else "")
-            else:
-                key = lambda name, rev: f"lstm.{l}.{name}_l0" + ("_reverse" if rev else "")
-            wih, bias, whh = [], [], []
-            for rev in (False, True):
-                wi = sd[key("weight_ih", rev)][perm]
-                if wi.shape[1] == 60:
-                    wi = torch.nn.functional.pad(wi, (0, 4))
-                wih.append(wi)
-                bias.append((sd[key("bias_ih", rev)] + sd[key("bias_hh", rev)])[perm])
-                whh.append(_lstm_whh_image(sd[key("weight_hh", rev)]))
-            w.lstm_wih[l] = self._up(torch.cat(wih, 0)).value
-            w.lstm_bias[l] = self._up(torch.cat(bias, 0)).value
-            w.lstm_whh[l] = self._up(torch.cat(whh, 0)).value
-        for l in range(w.num_linear):
-            w.lin_w[l] = self._up(sd[f"linear.{l}.weight"]).value
-            w.lin_b[l] = self._up(sd[f"linear.{l}.bias"]).value
-        w.cls_w = self._up(sd["classifier.weight"])
-        w.cls_b = self._up(sd["classifier.bias"])
+        pack_lstm_head(sd, w, lstm, self._up)
         # max_set_size None / 0 = a multi-label (non-powerset) checkpoint: sigmoid scores, no look-up table
         self.powerset = bool(max_set_size)
         if self.powerset:
@@ -155,6 +135,35 @@ class SegmentationPack:
         d = t.contiguous().to(self.device)
         self._keep.append(d)
         return C.c_void_p(d.data_ptr())
+
+
+def pack_lstm_head(sd: dict, w, lstm: dict, up):
+    """bi-LSTM stack (PyTorch gate order i, f, g, o; monolithic `lstm.weight_ih_l{k}` or split
+    `lstm.{k}.weight_ih_l0` keys, PyanNet.py:98-123 / SSeRiouSS.py:141-170), Linear head and classifier ->
+    the operand images shared by pa_seg_weights and pa_sser_weights."""
+    L = int(lstm["num_layers"])
+    perm = _lstm_row_perm()
+    for l in range(L):
+        if lstm["monolithic"]:
+            key = lambda name, rev: f"lstm.{name}_l{l}" + ("_reverse" if rev else "")
+        else:
+            key = lambda name, rev: f"lstm.{l}.{name}_l0" + ("_reverse" if rev else "")
+        wih, bias, whh = [], [], []
+        for rev in (False, True):
+            wi = sd[key("weight_ih", rev)][perm]
+            if wi.shape[1] == 60:
+                wi = torch.nn.functional.pad(wi, (0, 4))
+            wih.append(wi)
+            bias.append((sd[key("bias_ih", rev)] + sd[key("bias_hh", rev)])[perm])
+            whh.append(_lstm_whh_image(sd[key("weight_hh", rev)]))
+        w.lstm_wih[l] = up(torch.cat(wih, 0)).value
+        w.lstm_bias[l] = up(torch.cat(bias, 0)).value
+        w.lstm_whh[l] = up(torch.cat(whh, 0)).value
+    for l in range(w.num_linear):
+        w.lin_w[l] = up(sd[f"linear.{l}.weight"]).value
+        w.lin_b[l] = up(sd[f"linear.{l}.bias"]).value
+    w.cls_w = up(sd["classifier.weight"])
+    w.cls_b = up(sd["classifier.bias"])
 
 
 def pack_sincnet(sd: dict, w, up) -> torch.Tensor:
@@ -176,6 +185,179 @@ def pack_sincnet(sd: dict, w, up) -> torch.Tensor:
         cb[:60] = sd[f"sincnet.conv1d.{i}.bias"]
         setattr(w, f"conv{i}_b", up(cb))
     return taps
+
+
+#: constructor arguments of torchaudio's WavLM-base bundles (torchaudio.pipelines.WAVLM_BASE / _BASE_PLUS ->
+#: torchaudio.models.wavlm_base()), what SSeRiouSS's default `wav2vec="WAVLM_BASE"` builds (SSeRiouSS.py:100-109)
+WAV2VEC_BUNDLES = {
+    name: dict(extractor_mode="group_norm",
+               extractor_conv_layer_config=[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2,
+               extractor_conv_bias=False, encoder_embed_dim=768, encoder_pos_conv_kernel=128,
+               encoder_pos_conv_groups=16, encoder_num_layers=12, encoder_num_heads=12, encoder_num_buckets=320,
+               encoder_max_distance=800, encoder_ff_interm_features=3072, encoder_layer_norm_first=False, wavlm=True)
+    for name in ("WAVLM_BASE", "WAVLM_BASE_PLUS")}
+
+
+def wav2vec_config(wav2vec) -> dict:
+    """hyper-parameter `wav2vec` of SSeRiouSS (a bundle name, or the keyword arguments of
+    torchaudio.models.wav2vec2_model) -> architecture description"""
+    if isinstance(wav2vec, str):
+        if wav2vec not in WAV2VEC_BUNDLES:
+            raise NotImplementedError(f"wav2vec bundle {wav2vec!r}: built are {sorted(WAV2VEC_BUNDLES)} and "
+                                      "explicit wav2vec2_model configurations")
+        return dict(WAV2VEC_BUNDLES[wav2vec])
+    cfg = dict(wav2vec)
+    cfg.setdefault("extractor_conv_layer_config", None)
+    if cfg["extractor_conv_layer_config"] is None:
+        cfg["extractor_conv_layer_config"] = [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2
+    cfg["wavlm"] = False
+    return cfg
+
+
+def relative_position_bucket(relative_positions: torch.Tensor, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """WavLM's bidirectional T5-style bucketing of k - q (wavlm_attention.py `_relative_positions_bucket`)"""
+    num_buckets //= 2
+    buckets = (relative_positions > 0).to(torch.long) * num_buckets
+    rel = torch.abs(relative_positions)
+    max_exact = num_buckets // 2
+    is_small = rel < max_exact
+    large = max_exact + (torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (num_buckets - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return buckets + torch.where(is_small, rel, large)
+
+
+class SSeRiouSSPack:
+    """Device-resident, kernel-ready SSeRiouSS weights + the `pa_sser_weights` struct
+    (models/segmentation/SSeRiouSS.py:84-215; state-dict names of torchaudio's wav2vec2 / WavLM modules:
+    wav2vec.feature_extractor.conv_layers.{i}.{conv,layer_norm}, wav2vec.encoder.feature_projection.*,
+    wav2vec.encoder.transformer.{pos_conv_embed.conv,layer_norm,layers.{i}.*}, wav2vec_weights, lstm.*,
+    linear.*, classifier.*)."""
+
+    def __init__(self, state_dict: dict, hparams: dict, num_classes: int, num_speakers: int,
+                 max_set_size, device: torch.device):
+        sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
+        cfg = wav2vec_config(hparams.get("wav2vec") or "WAVLM_BASE")
+        lstm = {"hidden_size": 128, "num_layers": 4, "bidirectional": True, "monolithic": True,
+                **(hparams.get("lstm") or {})}
+        linear = {"hidden_size": 128, "num_layers": 2, **(hparams.get("linear") or {})}
+        if lstm["hidden_size"] != 128 or not lstm["bidirectional"]:
+            raise NotImplementedError("kernels are built for bi-LSTM(128)")
+        if linear["num_layers"] > 0 and linear["hidden_size"] != 128:
+            raise NotImplementedError("kernels are built for Linear(128) heads")
+        self.device = device
+        self.cfg = cfg
+        self._keep: list[torch.Tensor] = []
+        self._bias_cache: dict = {}
+        up = self._up
+        w = ffi.SserWeights()
+        shapes = cfg["extractor_conv_layer_config"]
+        D, H, F = cfg["encoder_embed_dim"], cfg["encoder_num_heads"], cfg["encoder_ff_interm_features"]
+        nl = cfg["encoder_num_layers"]
+        if len(shapes) > ffi.PA_W2V_MAX_CONV or nl > ffi.PA_W2V_MAX_LAYERS:
+            raise NotImplementedError("at most 8 feature-extractor and 24 transformer layers are built")
+        if any(c % 32 for c, _, _ in shapes) or D % 32 or F % 32 or (D // H) % 32 or shapes[0][1] > 16:
+            raise NotImplementedError("channel counts, embed_dim, ff size and head size must be multiples of 32")
+        w.num_conv = len(shapes)
+        w.extractor_layer_norm = int(cfg["extractor_mode"] == "layer_norm")
+        fe = "wav2vec.feature_extractor.conv_layers"
+        cin = 1
+        for i, (cout, k, s_) in enumerate(shapes):
+            w.conv_channels[i], w.conv_kernel[i], w.conv_stride[i] = cout, k, s_
+            cw = sd[f"{fe}.{i}.conv.weight"]                       # (cout, cin, k)
+            packed = cw.reshape(cout, k) if i == 0 else cw.permute(0, 2, 1).reshape(cout, k * cin)
+            w.conv_w[i] = up(packed).value
+            w.conv_b[i] = up(sd[f"{fe}.{i}.conv.bias"]).value if f"{fe}.{i}.conv.bias" in sd else None
+            if f"{fe}.{i}.layer_norm.weight" in sd:
+                w.conv_norm_g[i] = up(sd[f"{fe}.{i}.layer_norm.weight"]).value
+                w.conv_norm_b[i] = up(sd[f"{fe}.{i}.layer_norm.bias"]).value
+            cin = cout
+        enc = "wav2vec.encoder"
+        w.proj_ln_g, w.proj_ln_b = up(sd[f"{enc}.feature_projection.layer_norm.weight"]), \
+            up(sd[f"{enc}.feature_projection.layer_norm.bias"])
+        w.proj_w, w.proj_b = up(sd[f"{enc}.feature_projection.projection.weight"]), \
+            up(sd[f"{enc}.feature_projection.projection.bias"])
+        # positional convolution: weight_norm(dim=2) materialised, w = v * g / ||v||_{dims 0,1}
+        pc = f"{enc}.transformer.pos_conv_embed.conv"
+        if f"{pc}.parametrizations.weight.original0" in sd:
+            g_, v_ = sd[f"{pc}.parametrizations.weight.original0"], sd[f"{pc}.parametrizations.weight.original1"]
+        elif f"{pc}.weight_g" in sd:
+            g_, v_ = sd[f"{pc}.weight_g"], sd[f"{pc}.weight_v"]
+        else:
+            g_, v_ = None, sd[f"{pc}.weight"]
+        pw = v_ if g_ is None else v_ * (g_ / torch.linalg.vector_norm(v_, dim=(0, 1), keepdim=True))
+        groups, KW = cfg["encoder_pos_conv_groups"], cfg["encoder_pos_conv_kernel"]
+        CG = D // groups                                           # (D, CG, KW) -> [g][j][ci][co]
+        w.pos_w = up(pw.reshape(groups, CG, CG, KW).permute(0, 3, 2, 1))
+        w.pos_b = up(sd[f"{pc}.bias"])
+        w.pos_kernel, w.pos_groups = KW, groups
+        w.enc_ln_g, w.enc_ln_b = up(sd[f"{enc}.transformer.layer_norm.weight"]), \
+            up(sd[f"{enc}.transformer.layer_norm.bias"])
+        w.embed_dim, w.num_layers, w.num_heads, w.ff_dim = D, nl, H, F
+        w.layer_norm_first, w.wavlm = int(bool(cfg["encoder_layer_norm_first"])), int(cfg["wavlm"])
+        for i in range(nl):
+            lp = f"{enc}.transformer.layers.{i}"
+            Lw = w.layers[i]
+            if cfg["wavlm"]:
+                ipw, ipb = sd[f"{lp}.attention.attention.in_proj_weight"], sd[f"{lp}.attention.attention.in_proj_bias"]
+                qk_w, qk_b, v_w, v_b = ipw[:2 * D], ipb[:2 * D], ipw[2 * D:], ipb[2 * D:]
+                ow, ob = sd[f"{lp}.attention.attention.out_proj.weight"], sd[f"{lp}.attention.attention.out_proj.bias"]
+                Lw.gate_w = up(sd[f"{lp}.attention.gru_rel_pos_linear.weight"])
+                Lw.gate_b = up(sd[f"{lp}.attention.gru_rel_pos_linear.bias"])
+                Lw.gate_const = up(sd[f"{lp}.attention.gru_rel_pos_const"].reshape(-1))
+            else:
+                qk_w = torch.cat([sd[f"{lp}.attention.q_proj.weight"], sd[f"{lp}.attention.k_proj.weight"]])
+                qk_b = torch.cat([sd[f"{lp}.attention.q_proj.bias"], sd[f"{lp}.attention.k_proj.bias"]])
+                v_w, v_b = sd[f"{lp}.attention.v_proj.weight"], sd[f"{lp}.attention.v_proj.bias"]
+                ow, ob = sd[f"{lp}.attention.out_proj.weight"], sd[f"{lp}.attention.out_proj.bias"]
+            Lw.qk_w, Lw.qk_b, Lw.v_w, Lw.out_w = up(qk_w), up(qk_b), up(v_w), up(ow)
+            # soft-max rows sum to 1: P (V + 1 b_v^T) = P V + b_v^T  ->  fold W_o b_v into the output bias
+            Lw.out_b = up((ob.double() + ow.double() @ v_b.double()).float())
+            Lw.ln1_g, Lw.ln1_b = up(sd[f"{lp}.layer_norm.weight"]), up(sd[f"{lp}.layer_norm.bias"])
+            Lw.ff1_w = up(sd[f"{lp}.feed_forward.intermediate_dense.weight"])
+            Lw.ff1_b = up(sd[f"{lp}.feed_forward.intermediate_dense.bias"])
+            Lw.ff2_w = up(sd[f"{lp}.feed_forward.output_dense.weight"])
+            Lw.ff2_b = up(sd[f"{lp}.feed_forward.output_dense.bias"])
+            Lw.ln2_g, Lw.ln2_b = up(sd[f"{lp}.final_layer_norm.weight"]), up(sd[f"{lp}.final_layer_norm.bias"])
+        self.rel_attn_embed = sd.get(f"{enc}.transformer.layers.0.attention.rel_attn_embed.weight")
+        w.use_layer = int(hparams.get("wav2vec_layer", -1))
+        if w.use_layer < 0:
+            mix = torch.softmax(sd["wav2vec_weights"], dim=0)      # SSeRiouSS.py:309-311
+            for i in range(nl):
+                w.layer_mix[i] = float(mix[i])
+        w.lstm_layers = int(lstm["num_layers"])
+        w.lstm_hidden, w.lstm_bidir = 128, 1
+        w.num_linear, w.linear_hidden = int(linear["num_layers"]), 128
+        w.num_classes, w.num_speakers = num_classes, num_speakers
+        pack_lstm_head(sd, w, lstm, up)
+        self.powerset = bool(max_set_size)
+        if self.powerset:
+            self.mapping = powerset_mapping(num_speakers, max_set_size)
+            assert self.mapping.shape[0] == num_classes
+            w.powerset_map = up(self.mapping)
+        else:
+            assert num_classes == num_speakers
+            self.mapping = None
+            w.powerset_map = None
+        self.struct = w
+
+    def relative_bias(self, num_frames: int):
+        """[H][T][T] table rel_attn_embed[bucket(k - q)] of a chunk with T frames (compute_bias of the first
+        layer, shared by all layers); None for a wav2vec 2.0 encoder"""
+        if self.rel_attn_embed is None:
+            return None
+        if num_frames not in self._bias_cache:
+            pos = torch.arange(num_frames, dtype=torch.long)
+            bucket = relative_position_bucket(pos[None, :] - pos[:, None], self.cfg["encoder_num_buckets"],
+                                              self.cfg["encoder_max_distance"])
+            table = self.rel_attn_embed[bucket].permute(2, 0, 1).contiguous()
+            self._bias_cache[num_frames] = table.to(self.device)
+        return self._bias_cache[num_frames]
+
+    def _up(self, t: torch.Tensor):
+        d = t.contiguous().to(self.device)
+        self._keep.append(d)
+        return C.c_void_p(d.data_ptr())
 
 
 class XVectorPack:

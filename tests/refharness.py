@@ -326,11 +326,17 @@ def _signal_standins() -> dict:
     compliance.__path__ = []
     functional = _module("torchaudio.functional", resample=oaudio.resample)
     transforms = _module("torchaudio.transforms", MFCC=_Anything)     # (XVectorMFCC is not on the path)
-    torchaudio = _module("torchaudio", compliance=compliance, functional=functional, transforms=transforms)
+    # torchaudio's wav2vec 2.0 / WavLM (SSeRiouSS.py:100-124): oracle/wav2vec2.py, unpinned
+    import oracle.wav2vec2 as ow
+    models = _module("torchaudio.models", wav2vec2_model=ow.wav2vec2_model, wavlm_model=ow.wavlm_model)
+    pipelines = _module("torchaudio.pipelines", **ow.PIPELINES)
+    torchaudio = _module("torchaudio", compliance=compliance, functional=functional, transforms=transforms,
+                         models=models, pipelines=pipelines)
     torchaudio.__path__ = []
     return {"asteroid_filterbanks": asteroid, "torchaudio": torchaudio, "torchaudio.compliance": compliance,
             "torchaudio.compliance.kaldi": kaldi, "torchaudio.functional": functional,
-            "torchaudio.transforms": transforms}
+            "torchaudio.transforms": transforms, "torchaudio.models": models,
+            "torchaudio.pipelines": pipelines}
 
 
 class _Anything:

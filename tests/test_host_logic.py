@@ -267,3 +267,117 @@ def test_xvector_pack_folds_batchnorm_forward():
         got = stats @ ew[:, :stats.shape[1]].T + eb
     assert ew.shape[1] == 3008 and torch.count_nonzero(ew[:, 3000:]) == 0
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def _host_array(pointer, *shape):
+    """a pa_*_weights pointer field of a pack built on the CPU device -> torch tensor view (what the kernels
+    would read)"""
+    import ctypes
+    n = int(np.prod(shape))
+    addr = pointer if isinstance(pointer, int) else pointer.value
+    return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)).reshape(shape).copy())
+
+
+def _emulate_sser_encoder(pack, wav):
+    """pa_sser_forward's encoder, operation for operation, in plain torch on the PACKED weights
+    (csrc/sser_forward.cpp + w2v.hip): validates every host-side layout / fold of SSeRiouSSPack."""
+    import torch.nn.functional as F
+    w, cfg = pack.struct, pack.cfg
+    B = wav.shape[0]
+    D, H, FF, nl = w.embed_dim, w.num_heads, w.ff_dim, w.num_layers
+    hd = D // H
+    x = wav
+    cin = 1
+    for l in range(w.num_conv):
+        cout, k, s = w.conv_channels[l], w.conv_kernel[l], w.conv_stride[l]
+        W = _host_array(w.conv_w[l], cout, k * cin)
+        win = x.unfold(1, k, s) if l == 0 else x.unfold(1, k, s).permute(0, 1, 3, 2).reshape(B, -1, k * cin)
+        x = win @ W.T
+        if w.conv_b[l]:
+            x = x + _host_array(w.conv_b[l], cout)
+        if w.extractor_layer_norm:
+            x = F.gelu(F.layer_norm(x, (cout,), _host_array(w.conv_norm_g[l], cout), _host_array(w.conv_norm_b[l], cout)))
+        elif l == 0:
+            m, v = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+            x = F.gelu((x - m) / torch.sqrt(v + 1e-5) * _host_array(w.conv_norm_g[0], cout) + _host_array(w.conv_norm_b[0], cout))
+        else:
+            x = F.gelu(x)
+        cin = cout
+    T = x.shape[1]
+    x = F.layer_norm(x, (cin,), _host_array(w.proj_ln_g, cin), _host_array(w.proj_ln_b, cin))
+    x = x @ _host_array(w.proj_w, D, cin).T + _host_array(w.proj_b, D)
+    G, KW = w.pos_groups, w.pos_kernel
+    CG = D // G
+    w3 = _host_array(w.pos_w, G, KW, CG, CG)
+    xp = F.pad(x, (0, 0, KW // 2, KW // 2))                                  # zero padding in time
+    pos = torch.zeros_like(x)
+    for g in range(G):
+        for j in range(KW):
+            pos[:, :, g * CG:(g + 1) * CG] += xp[:, j:j + T, g * CG:(g + 1) * CG] @ w3[g, j]
+    x = x + F.gelu(pos + _host_array(w.pos_b, D))
+    if w.layer_norm_first:
+        x = F.layer_norm(x, (D,), _host_array(w.enc_ln_g, D), _host_array(w.enc_ln_b, D))
+    bias = pack.relative_bias(T)
+    outs = []
+    for l in range(nl):
+        L = w.layers[l]
+        ln1 = lambda t: F.layer_norm(t, (D,), _host_array(L.ln1_g, D), _host_array(L.ln1_b, D))   # noqa: E731
+        ln2 = lambda t: F.layer_norm(t, (D,), _host_array(L.ln2_g, D), _host_array(L.ln2_b, D))   # noqa: E731
+        a = ln1(x) if w.layer_norm_first else x
+        qk = a @ _host_array(L.qk_w, 2 * D, D).T + _host_array(L.qk_b, 2 * D)
+        v = a @ _host_array(L.v_w, D, D).T
+        q, k = (t.view(B, T, H, hd).transpose(1, 2) for t in (qk[..., :D], qk[..., D:]))
+        s = q @ k.transpose(-1, -2) / np.sqrt(hd)
+        if bias is not None:
+            u = a.view(B, T, H, hd).transpose(1, 2) @ _host_array(L.gate_w, 8, hd).T + _host_array(L.gate_b, 8)
+            ga, gb = torch.sigmoid(u[..., :4].sum(-1)), torch.sigmoid(u[..., 4:].sum(-1))
+            gate = ga * (gb * _host_array(L.gate_const, H).view(1, H, 1) - 1.0) + 2.0
+            s = s + gate.unsqueeze(-1) * bias
+        o = (torch.softmax(s, -1) @ v.view(B, T, H, hd).transpose(1, 2)).transpose(1, 2).reshape(B, T, D)
+        x1 = x + o @ _host_array(L.out_w, D, D).T + _host_array(L.out_b, D)
+        def ff(t):
+            hidden = F.gelu(t @ _host_array(L.ff1_w, FF, D).T + _host_array(L.ff1_b, FF))
+            return hidden @ _host_array(L.ff2_w, D, FF).T + _host_array(L.ff2_b, D)
+        if w.layer_norm_first:
+            x = x1 + ff(ln2(x1))
+        else:
+            a1 = ln1(x1)
+            x = ln2(a1 + ff(a1))
+        outs.append(x)
+    if w.use_layer < 0:
+        return sum(w.layer_mix[l] * outs[l] for l in range(nl))
+    return outs[max(1, w.use_layer) - 1]
+
+
+@pytest.mark.parametrize("config,layer", [("tiny", -1), ("tiny", 2), ("wavlm_small", -1)])
+def test_sseriouss_pack_layouts(config, layer):
+    """SSeRiouSSPack (weights.py): strided convolutions as GEMM operands, q|k / v split with the v bias folded
+    into the output projection, materialised weight_norm of the positional convolution in [g][j][ci][co] order,
+    the relative-position table, softmax'd layer weights -- the packed chain equals the oracle's encoder."""
+    import oracle.models as om
+    import oracle.wav2vec2 as ow
+    from pyannote_audio_amd.weights import SSeRiouSSPack
+    if config == "tiny":
+        wav2vec = dict(om.TINY_WAV2VEC2)
+        model = om.seeded_sseriouss(wav2vec=wav2vec, num_layers=1, wav2vec_layer=layer)
+    else:   # a small WavLM: group_norm extractor, post-LN encoder, gated relative position bias
+        small = dict(ow.WAVLM_BASE, extractor_conv_layer_config=[(64, 10, 5), (64, 3, 2), (64, 2, 2)],
+                     encoder_embed_dim=128, encoder_num_layers=2, encoder_num_heads=4, encoder_pos_conv_kernel=16,
+                     encoder_pos_conv_groups=4, encoder_ff_interm_features=256, encoder_num_buckets=40,
+                     encoder_max_distance=100)
+        ow.PIPELINES["_TEST_SMALL"] = ow._Bundle(small)
+        import pyannote_audio_amd.weights as pw
+        pw.WAV2VEC_BUNDLES["_TEST_SMALL"] = dict(
+            {k: v for k, v in small.items() if k in pw.WAV2VEC_BUNDLES["WAVLM_BASE"]}, wavlm=True)
+        wav2vec = "_TEST_SMALL"
+        model = om.seeded_sseriouss(wav2vec=wav2vec, num_layers=1, wav2vec_layer=layer)
+    hparams = {"wav2vec": wav2vec, "wav2vec_layer": layer, "lstm": {"num_layers": 1}}
+    pack = SSeRiouSSPack(model.state_dict(), hparams, 7, 3, 2, torch.device("cpu"))
+    g = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(2, 4000, generator=g)).clamp(-1, 1)
+    with torch.inference_mode():
+        outs, _ = model.wav2vec.extract_features(wav, num_layers=None if layer < 0 else layer)
+        want = torch.stack(outs, dim=-1) @ torch.softmax(model.wav2vec_weights, 0) if layer < 0 else outs[-1]
+        got = _emulate_sser_encoder(pack, wav)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-5), (got - want).abs().max()

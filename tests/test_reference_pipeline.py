@@ -316,3 +316,37 @@ def test_reference_xvector_sincnet_equals_oracle(ref):
                 lower = middle
     from pyannote_audio_amd.speaker_verification import first_true
     assert upper == first_true(lambda n: product.num_frames(n) > 0, 2, 8000)
+
+
+@pytest.mark.parametrize("wav2vec,layer", [("WAVLM_BASE", -1), ("tiny", -1), ("tiny", 2)])
+def test_reference_sseriouss_equals_oracle(ref, tmp_path, wav2vec, layer):
+    """f3: the reference's `SSeRiouSS` (models/segmentation/SSeRiouSS.py:42-328 -- layer weighting :307-313,
+    LSTM :315-322, head :324-328, frame geometry :217-287), loaded by the reference's loader from a checkpoint
+    the product wrote, vs oracle.models.SSeRiouSS.  BOTH run on oracle/wav2vec2.py, the (unpinned) restatement
+    of torchaudio's wav2vec 2.0 / WavLM encoder: this pins the reference's own file, not torchaudio."""
+    import oracle.models as om
+    from pyannote_audio_amd.model import save_checkpoint, segmentation_specifications
+    config = "WAVLM_BASE" if wav2vec == "WAVLM_BASE" else dict(om.TINY_WAV2VEC2)
+    ours = om.seeded_sseriouss(wav2vec=config, num_layers=2, wav2vec_layer=layer)
+    hparams = {"wav2vec": config, "wav2vec_frozen": False, "wav2vec_layer": layer,
+               "lstm": {"hidden_size": 128, "num_layers": 2, "bidirectional": True, "monolithic": True,
+                        "dropout": 0.0}, "linear": {"hidden_size": 128, "num_layers": 2},
+               "sample_rate": 16000, "num_channels": 1}
+    path = os.path.join(str(tmp_path), "pytorch_model.bin")
+    save_checkpoint(path, ours.state_dict(), hparams,
+                    ("pyannote.audio.models.segmentation.SSeRiouSS", "SSeRiouSS"), segmentation_specifications(10.0))
+    theirs = ref["Model"].from_pretrained(path)
+    assert type(theirs).__name__ == "SSeRiouSS" and list(theirs.state_dict()) == list(ours.state_dict())
+    g = torch.Generator().manual_seed(4)
+    wav = (0.1 * torch.randn(2, 1, 24000, generator=g)).clamp(-1, 1)
+    with torch.inference_mode():
+        want, got = theirs(wav), ours(wav)
+    assert want.shape == got.shape and torch.equal(got, want)
+    import pyannote_audio_amd.model as pm
+    product = pm.SSeRiouSS.__new__(pm.SSeRiouSS)
+    product.hparams = hparams
+    for n in (24000, 160000, 80000, 400, 399):
+        assert product.num_frames(n) == theirs.num_frames(n)
+    assert product.receptive_field_size(1) == theirs.receptive_field_size(1)
+    assert product.receptive_field_size(2) == theirs.receptive_field_size(2)
+    assert product.receptive_field_center(0) == theirs.receptive_field_center(0)
