@@ -20,6 +20,8 @@
 //   * all heap operations (build, change_value, remove_min, sift_up/down) are executed by one lane in
 //     exactly SciPy's order, including the ascending-z order of the lower-bound refresh.
 // hipcc-flags: -ffp-contract=off
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pa {
@@ -408,6 +410,321 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
   }
 }
 
+// =============================================================================================
+// Multi-workgroup form.  The O(N) part of a merge -- the Lance-Williams update of column y, the neighbour
+// fix-ups, the lower-bound candidates and the nearest-neighbour scan of row y -- reads ~2 N scattered
+// distances; one CU sustains only ~60-100 GB/s of such traffic, which is what made the single workgroup take
+// 240 us per merge at N = 57 k (13.9 s for the joint clustering of 8 audio-hours).  Here G workgroups, all on
+// ONE XCD (workgroup w runs on XCD w mod 8: the launch has 8 G workgroups and only every 8th works, so the
+// matrix stays coherent in one L2), split that pass; workgroup 0 alone keeps SciPy's heap and replays its
+// updates in SciPy's order, so the dendrogram stays bit-identical.  Two grid barriers per merge (fence +
+// atomic counter + generation word, ~2 us each inside an XCD):
+//     WG0: find the closest pair (lower-bound repairs on its own), record the merge, publish (x, y, sizes)
+//     -- barrier --   all: one slice of the z pass; refreshed rows appended to a global pending list,
+//                     per-workgroup nearest neighbour of y
+//     -- barrier --   WG0: rank-sort the pending rows, heap updates by lane 0, neighbour of y
+// `mind[z]` mirrors the heap value of key z (SciPy's min_dist[z]) in global memory for the other workgroups.
+// =============================================================================================
+struct LkShared {          // global memory, zero-initialised by the launcher
+  int bar_count, bar_gen;
+  int x, y, nx, ny;
+  double dist;
+  int npend;
+  int pad_;
+  MinPair red[32];
+  int pend_z[LK_PEND];
+  double pend_d[LK_PEND];
+};
+
+__device__ __forceinline__ void lk_grid_barrier(LkShared* sh, int G) {
+  __threadfence();                      // every thread: its stores are visible device-wide
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int gen = __atomic_load_n(&sh->bar_gen, __ATOMIC_RELAXED);
+    if (atomicAdd(&sh->bar_count, 1) == G - 1) {
+      atomicExch(&sh->bar_count, 0);
+      __threadfence();
+      atomicAdd(&sh->bar_gen, 1);
+    } else {
+      while (__atomic_load_n(&sh->bar_gen, __ATOMIC_RELAXED) == gen) __builtin_amdgcn_s_sleep(2);
+    }
+    __threadfence();                    // acquire: drop this CU's stale L1 lines
+  }
+  __syncthreads();
+}
+
+template <typename IT, bool LDS_HEAP>
+__global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict__ D, int n,
+                                                               double* __restrict__ Z,
+                                                               int* __restrict__ size,
+                                                               int* __restrict__ cluster_id,
+                                                               double* __restrict__ g_hv,
+                                                               int* __restrict__ g_kbi,
+                                                               int* __restrict__ g_ibk,
+                                                               int* __restrict__ g_nb,
+                                                               double* __restrict__ mind,
+                                                               unsigned int* __restrict__ cand,
+                                                               LkShared* __restrict__ sh, int G,
+                                                               long long* __restrict__ stats) {
+  if ((blockIdx.x & 7) != 0) return;     // only the workgroups of one XCD take part
+  const int wg = blockIdx.x >> 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ MinPair red[LK_W];
+  __shared__ int sh_x, sh_y, sh_ok;
+  __shared__ double sh_dist;
+  __shared__ int sort_z[LK_PEND];
+  __shared__ double sort_d[LK_PEND];
+  const int tid = threadIdx.x;
+  const int hn = n - 1;
+  int* nb = g_nb;                        // neighbour candidates live in global memory (every workgroup writes them)
+
+  Heap<IT> heap;
+  if (LDS_HEAP) {
+    heap.v = reinterpret_cast<double*>(lds_raw);
+    heap.kbi = reinterpret_cast<IT*>(heap.v + hn);
+    heap.ibk = heap.kbi + hn;
+  } else {
+    heap.v = g_hv;
+    heap.kbi = reinterpret_cast<IT*>(g_kbi);
+    heap.ibk = reinterpret_cast<IT*>(g_ibk);
+  }
+  heap.size = hn;
+  const int cand_words = (n + 31) / 32;
+
+  // ---- initialisation, split over the workgroups: sizes, ids, candidate bitmap, nearest neighbours
+  for (int i = wg * LK_T + tid; i < n; i += G * LK_T) {
+    size[i] = 1;
+    cluster_id[i] = i;
+  }
+  for (int i = wg * LK_T + tid; i < cand_words; i += G * LK_T) cand[i] = 0u;
+  {
+    const int lane = tid & 63, w = tid >> 6;
+    for (int x = wg * LK_W + w; x < n - 1; x += G * LK_W) {
+      MinPair best{__builtin_inf(), -1};
+      const long base = (long)n * x - ((long)x * (x + 1) / 2) - x - 1;
+      for (int i = x + 1 + lane; i < n; i += 64) {
+        const double d = D[base + i];
+        if (d < best.d) {
+          best.d = d;
+          best.i = i;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        MinPair other;
+        other.d = __shfl_xor(best.d, o, 64);
+        other.i = __shfl_xor(best.i, o, 64);
+        best = min_pair(best, other);
+      }
+      if (lane == 0) {
+        nb[x] = best.i;
+        mind[x] = best.i < 0 ? __builtin_inf() : best.d;
+      }
+    }
+  }
+  lk_grid_barrier(sh, G);
+  if (wg == 0) {
+    for (int x = tid; x < hn; x += LK_T) {
+      heap.v[x] = mind[x];
+      heap.kbi[x] = (IT)x;
+      heap.ibk[x] = (IT)x;
+    }
+    __syncthreads();
+    if (tid == 0) heap.build();
+    __syncthreads();
+  }
+
+  long long st_retry = 0, st_cand = 0, st_ovf = 0, st_c0 = 0, st_c1 = 0, st_c2 = 0, st_c3 = 0;
+  for (int k = 0; k < n - 1; ++k) {
+    long long tc = __builtin_readcyclecounter();
+    if (wg == 0) {
+      // ---- find the two closest clusters (lower-bound repairs) and record the merge
+      int x = 0, y = 0;
+      double dist = 0.0;
+      for (int it = 0; it < n - k; ++it) {
+        if (tid == 0) {
+          const int hx = heap.kbi[0];
+          const double hd = heap.v[0];
+          const int hy = nb[hx];
+          sh_x = hx;
+          sh_y = hy;
+          sh_dist = hd;
+          sh_ok = (hy >= 0 && hd == D[cidx(n, hx, hy)]) ? 1 : 0;
+        }
+        __syncthreads();
+        x = sh_x;
+        y = sh_y;
+        dist = sh_dist;
+        const int ok = sh_ok;
+        if (ok) break;
+        const MinPair p = block_find_min(D, size, n, x, red);
+        y = p.i;
+        dist = p.d;
+        if (tid == 0) {
+          nb[x] = y;
+          heap.change_value(x, dist);
+          mind[x] = dist;
+          ++st_retry;
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        heap.remove_min();
+        int id_x = cluster_id[x], id_y = cluster_id[y];
+        const int nx = size[x], ny = size[y];
+        if (id_x > id_y) {
+          const int t = id_x;
+          id_x = id_y;
+          id_y = t;
+        }
+        Z[4 * (long)k + 0] = (double)id_x;
+        Z[4 * (long)k + 1] = (double)id_y;
+        Z[4 * (long)k + 2] = dist;
+        Z[4 * (long)k + 3] = (double)(nx + ny);
+        size[x] = 0;
+        size[y] = nx + ny;
+        cluster_id[y] = n + k;
+        sh->x = x;
+        sh->y = y;
+        sh->nx = nx;
+        sh->ny = ny;
+        sh->dist = dist;
+        sh->npend = 0;
+      }
+      const long long t2 = __builtin_readcyclecounter();
+      st_c0 += t2 - tc;
+      tc = t2;
+    }
+    lk_grid_barrier(sh, G);
+    {
+      const long long t2 = __builtin_readcyclecounter();
+      st_c1 += t2 - tc;
+      tc = t2;
+    }
+    const int x = sh->x, y = sh->y, nx = sh->nx, ny = sh->ny;
+    const double dist = sh->dist;
+    // ---- this workgroup's slices of the pass over all clusters z
+    MinPair best{__builtin_inf(), -1};
+    for (int z0 = wg * 4 * LK_T + tid; z0 < n; z0 += G * 4 * LK_T) {
+      bool act[4];
+      long izy[4];
+      double d_xi[4], d_yi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int z = z0 + u * LK_T;
+        act[u] = z < n && z != y && size[z] != 0;
+        izy[u] = act[u] ? cidx(n, z, y) : 0;
+        d_xi[u] = act[u] ? D[cidx(n, z, x)] : 0.0;
+        d_yi[u] = act[u] ? D[izy[u]] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!act[u]) continue;
+        const int z = z0 + u * LK_T;
+        const double nd = sqrt(
+            (((nx * d_xi[u] * d_xi[u]) + (ny * d_yi[u] * d_yi[u])) - ((nx * ny) * dist * dist) / (nx + ny)) /
+            (nx + ny));
+        D[izy[u]] = nd;
+        if (z < y) {
+          if (z < x && nb[z] == x) nb[z] = y;
+          if (nd < mind[z]) {
+            nb[z] = y;
+            atomicOr(&cand[z >> 5], 1u << (z & 31));
+            const int slot = atomicAdd(&sh->npend, 1);
+            if (slot < LK_PEND) {
+              sh->pend_z[slot] = z;
+              sh->pend_d[slot] = nd;
+            }
+          }
+        } else if (nd < best.d) {
+          best.d = nd;
+          best.i = z;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      MinPair other;
+      other.d = __shfl_xor(best.d, o, 64);
+      other.i = __shfl_xor(best.i, o, 64);
+      best = min_pair(best, other);
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+      MinPair r = red[0];
+#pragma unroll
+      for (int q = 1; q < LK_W; ++q) r = min_pair(r, red[q]);
+      sh->red[wg] = r;
+    }
+    {
+      const long long t2 = __builtin_readcyclecounter();
+      st_c2 += t2 - tc;
+      tc = t2;
+    }
+    lk_grid_barrier(sh, G);
+    if (wg == 0) {
+      // ---- replay the heap updates in SciPy's order: ascending z < y, then row y
+      const int np = sh->npend;
+      if (np <= LK_PEND && tid < np) {
+        const int z = sh->pend_z[tid];
+        int rank = 0;
+        for (int q = 0; q < np; ++q) rank += sh->pend_z[q] < z ? 1 : 0;
+        sort_z[rank] = z;
+        sort_d[rank] = sh->pend_d[tid];
+        cand[z >> 5] = 0u;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        st_cand += np;
+        if (np <= LK_PEND) {
+          for (int q = 0; q < np; ++q) {
+            heap.change_value(sort_z[q], sort_d[q]);
+            mind[sort_z[q]] = sort_d[q];
+          }
+        } else {
+          ++st_ovf;
+          const int words = (y + 31) / 32;
+          for (int wi = 0; wi < words; ++wi) {
+            unsigned int m = cand[wi];
+            if (!m) continue;
+            cand[wi] = 0u;
+            while (m) {
+              const int bit = __builtin_ctz(m);
+              m &= m - 1;
+              const int z = wi * 32 + bit;
+              const double dz = D[cidx(n, z, y)];
+              heap.change_value(z, dz);
+              mind[z] = dz;
+            }
+          }
+        }
+        if (y < n - 1) {
+          MinPair r = sh->red[0];
+          for (int q = 1; q < G; ++q) r = min_pair(r, sh->red[q]);
+          if (r.i != -1) {
+            nb[y] = r.i;
+            heap.change_value(y, r.d);
+            mind[y] = r.d;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    st_c3 += __builtin_readcyclecounter() - tc;
+  }
+  if (wg == 0 && tid == 0 && stats != nullptr) {
+    stats[0] = st_retry;
+    stats[1] = st_cand;
+    stats[2] = st_ovf;
+    stats[3] = st_c0;
+    stats[4] = st_c1;
+    stats[5] = st_c2;
+    stats[6] = st_c3;
+    stats[7] = n;
+  }
+}
+
 constexpr size_t LK_LDS_MAX = 160 * 1024 - 7680;  // dynamic LDS budget (static part: ~6.5 KB)
 
 inline size_t lk_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -419,7 +736,18 @@ extern "C" {
 size_t pa_linkage_workspace_bytes(int n) {
   if (n < 2) return 0;
   const size_t ni = pa::lk_align(sizeof(int) * (size_t)n), nd = pa::lk_align(sizeof(double) * (size_t)n);
-  return 5 * ni + nd + 64;  // size, cluster_id, neighbour, kbi, ibk (int) + heap values (double) + 8 counters
+  // size, cluster_id, neighbour, kbi, ibk (int) + heap values, min_dist mirror (double) + candidate bitmap +
+  // the multi-workgroup mailbox + 8 counters
+  return 5 * ni + 2 * nd + pa::lk_align(4 * (size_t)((n + 31) / 32) + 16) + pa::lk_align(sizeof(pa::LkShared)) + 64;
+}
+
+// number of workgroups of the merge kernel: PA_LINKAGE_WGS overrides (1 = the single-workgroup kernel)
+static int lk_num_workgroups(int n) {
+  const char* e = getenv("PA_LINKAGE_WGS");
+  if (e != nullptr && atoi(e) >= 1) return atoi(e) > 32 ? 32 : atoi(e);
+  if (n < 3000) return 1;                 // two grid barriers per merge cost more than the pass saves
+  const int g = n / 1800;
+  return g < 2 ? 2 : (g > 16 ? 16 : g);   // <= 16: two concurrent merges (two processes) still fit one XCD
 }
 
 // D: condensed distance matrix (n*(n-1)/2 doubles), OVERWRITTEN.  Z: (n-1, 4) doubles, SciPy layout.
@@ -428,6 +756,7 @@ int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t
   if (n < 2) return 0;
   PA_REQUIRE(workspace_bytes >= pa_linkage_workspace_bytes(n), "pa_linkage_centroid_f64: workspace too small");
   const size_t ni = pa::lk_align(sizeof(int) * (size_t)n), nd = pa::lk_align(sizeof(double) * (size_t)n);
+  const size_t cand_bytes = 4 * (size_t)((n + 31) / 32) + 16;
   unsigned char* w = (unsigned char*)workspace;
   int* size = (int*)w;
   int* cid = (int*)(w + ni);
@@ -435,12 +764,30 @@ int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t
   int* kbi = (int*)(w + 3 * ni);
   int* ibk = (int*)(w + 4 * ni);
   double* hv = (double*)(w + 5 * ni);
-  long long* stats = (long long*)(w + 5 * ni + nd);
+  double* mind = (double*)(w + 5 * ni + nd);
+  unsigned int* cand = (unsigned int*)(w + 5 * ni + 2 * nd);
+  pa::LkShared* shared = (pa::LkShared*)(w + 5 * ni + 2 * nd + pa::lk_align(cand_bytes));
+  long long* stats = (long long*)(w + pa_linkage_workspace_bytes(n) - 64);
   hipStream_t st = (hipStream_t)stream;
-  const size_t cand_bytes = 4 * (size_t)((n + 31) / 32) + 16;
-  const size_t lds16 = (((size_t)(n - 1) * 14 + 15) & ~(size_t)15) + cand_bytes;
   // the merge loop is O(N^2) memory traffic in total; algorithmic bytes ~ 3 rows of 8*N per merge
   pa::ProfScope prof("k_linkage_centroid", stream, 9.0 * n * (double)n, 24.0 * n * (double)n);
+  const int G = lk_num_workgroups(n);
+  if (G > 1) {
+    if (hipMemsetAsync(shared, 0, sizeof(pa::LkShared), st) != hipSuccess) return 1;
+    const size_t lds_heap = ((size_t)(n - 1) * 12 + 15) & ~(size_t)15;
+    if (n <= 65535 && lds_heap <= pa::LK_LDS_MAX) {
+      (void)hipFuncSetAttribute((const void*)pa::k_linkage_centroid_mw<unsigned short, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa::LK_LDS_MAX);
+      hipLaunchKernelGGL((pa::k_linkage_centroid_mw<unsigned short, true>), dim3(8 * G), dim3(pa::LK_T), lds_heap,
+                         st, D, n, Z, size, cid, hv, kbi, ibk, nb, mind, cand, shared, G, stats);
+    } else {
+      hipLaunchKernelGGL((pa::k_linkage_centroid_mw<int, false>), dim3(8 * G), dim3(pa::LK_T), 0, st, D, n, Z,
+                         size, cid, hv, kbi, ibk, nb, mind, cand, shared, G, stats);
+    }
+    PA_CHECK_LAUNCH("pa_linkage_centroid_f64");
+    return 0;
+  }
+  const size_t lds16 = (((size_t)(n - 1) * 14 + 15) & ~(size_t)15) + cand_bytes;
   if (n <= 65535 && lds16 <= pa::LK_LDS_MAX) {
     // (set on every call: the attribute belongs to the current device, not to the process)
     (void)hipFuncSetAttribute((const void*)pa::k_linkage_centroid<unsigned short, true>,

@@ -1,29 +1,56 @@
-import sys, os, time
+"""Times the dendrogram merge kernel (csrc/linkage.hip) for 1 .. 16 workgroups and checks every variant against
+SciPy (small n) or against the single-workgroup kernel (large n).
+usage (GPU box): python tools/time_linkage.py [n ...]     (default 7000 20000 57000)
+If gpurun_out/bench_train_emb.npy exists (PA_BENCH_DUMP_EMB=1 python bench.py ...) it is timed first."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from scipy.cluster.hierarchy import linkage
 from scipy.spatial.distance import pdist
 from pyannote_audio_amd import distance
+
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-emb_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "bench_train_emb.npy")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(X, G):
+    os.environ["PA_LINKAGE_WGS"] = str(G)
+    distance.linkage_centroid(X[:64].copy(), dev)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    Z = distance.linkage_centroid(X.copy(), dev)
+    dt = time.perf_counter() - t
+    st = distance.last_linkage_stats
+    n = len(X)
+    return Z, dt, (f"retries/merge {st[0] / n:.2f} heap-updates/merge {st[1] / n:.2f} overflows {st[2]} "
+                   f"cycles(find, wait, pass, replay)/merge {[int(c / n) for c in st[3:7]]}")
+
+
+def sweep(name, X, scipy_check):
+    ref = None
+    if scipy_check:
+        t = time.perf_counter()
+        ref = linkage(pdist(X), "centroid")
+        print(f"{name}: scipy pdist + linkage {1e3 * (time.perf_counter() - t):.0f} ms", flush=True)
+    for G in (1, 2, 4, 8, 16):
+        Z, dt, info = run(X, G)
+        if ref is None:
+            ref = Z
+        print(f"{name}: n={len(X)} workgroups={G:2d} {1e3 * dt:8.1f} ms  identical={np.array_equal(Z, ref)}  {info}",
+              flush=True)
+
+
+emb_file = os.path.join(ROOT, "gpurun_out", "bench_train_emb.npy")
 if os.path.exists(emb_file):
-    X = np.load(emb_file); X = X / np.linalg.norm(X, axis=1, keepdims=True)
-    t = time.perf_counter(); Z = distance.linkage_centroid(X.copy(), dev); tg = time.perf_counter() - t
-    st = distance.last_linkage_stats; n = len(X)
-    print("bench embeddings n=%d gpu %.1f ms retries/merge %.2f heap-updates/merge %.2f overflows %d cycles %s" % (
-        n, tg * 1e3, st[0] / n, st[1] / n, st[2], [int(c / n) for c in st[3:7]]), flush=True)
-for n in (1000, 3000, 7000):
+    X = np.load(emb_file)
+    X = X / np.linalg.norm(X, axis=1, keepdims=True)
+    sweep("bench embeddings", X, True)
+for n in [int(a) for a in sys.argv[1:]] or [7000, 20000, 57000]:
     c = rng.standard_normal((4, 256))
     X = (c[rng.integers(0, 4, n)] + 0.6 * rng.standard_normal((n, 256))).astype(np.float32)
     X /= np.linalg.norm(X, axis=1, keepdims=True)
-    distance.linkage_centroid(X[:100], dev)
-    t = time.perf_counter(); Z = distance.linkage_centroid(X, dev); tg = time.perf_counter() - t
-    st = distance.last_linkage_stats
-    print("   retries/merge %.2f  heap-updates/merge %.2f  overflows %d  cycles(find,record,pass,replay)/merge %s" % (
-        st[0] / n, st[1] / n, st[2], [int(c / n) for c in st[3:7]]), flush=True)
-    if n <= 7000:
-        t = time.perf_counter(); Zs = linkage(pdist(X), "centroid"); ts = time.perf_counter() - t
-        print(n, f"gpu {tg*1e3:.1f} ms  scipy(pdist+linkage) {ts*1e3:.1f} ms  equal={np.array_equal(Z, Zs)}", flush=True)
-    else:
-        print(n, f"gpu {tg*1e3:.1f} ms", flush=True)
+    if n >= 20000:           # exact ties: duplicated rows
+        X[n // 2: n // 2 + 500] = X[:500]
+    sweep("synthetic", X, n <= 7000)
+os.environ.pop("PA_LINKAGE_WGS", None)
