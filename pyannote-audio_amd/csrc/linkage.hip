@@ -106,8 +106,25 @@ __device__ __forceinline__ MinPair min_pair(MinPair a, MinPair b) {
   return a;
 }
 
+// Accesses to data that ANOTHER workgroup of the multi-workgroup kernel writes or reads: relaxed agent-scope
+// atomics = `global_load / global_store ... sc1`: loads are served by L2 (never by this CU's L1, which no other
+// CU's store refreshes), stores go through to memory.  With sc1 on BOTH sides no fence is needed and the protocol
+// does not depend on where the workgroups run (MI355X_MICROARCH.md, "inter-workgroup visibility"); a
+// __threadfence() per barrier instead costs 3.5-10 us (L2 write-back + L1 invalidate) -- measured here: the
+// fenced version of this kernel was SLOWER than one workgroup at every size.
+template <bool COH, typename T>
+__device__ __forceinline__ T lk_ld(const T* p) {
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <typename T>
+__device__ __forceinline__ void lk_st(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // find_min_dist(n, D, size, x): nearest active neighbour of x among indices > x.  All threads call;
 // result valid in every thread.  `red` = LK_W MinPairs of LDS.
+template <bool COH = false>
 __device__ MinPair block_find_min(const double* __restrict__ D, const int* __restrict__ size, int n,
                                   int x, MinPair* red) {
   MinPair best{__builtin_inf(), -1};
@@ -119,8 +136,8 @@ __device__ MinPair block_find_min(const double* __restrict__ D, const int* __res
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * LK_T;
-      act[u] = i < n && size[i] != 0;
-      d[u] = act[u] ? D[base + i] : 0.0;
+      act[u] = i < n && lk_ld<COH>(size + i) != 0;
+      d[u] = act[u] ? lk_ld<COH>(D + base + i) : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -423,6 +440,7 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
 //     -- barrier --   all: one slice of the z pass; refreshed rows appended to a global pending list,
 //                     per-workgroup nearest neighbour of y
 //     -- barrier --   WG0: rank-sort the pending rows, heap updates by lane 0, neighbour of y
+// Everything two workgroups share is read and written with sc1 accesses (lk_ld / lk_st): no fences.
 // `mind[z]` mirrors the heap value of key z (SciPy's min_dist[z]) in global memory for the other workgroups.
 // =============================================================================================
 struct LkShared {          // global memory, zero-initialised by the launcher
@@ -436,19 +454,22 @@ struct LkShared {          // global memory, zero-initialised by the launcher
   double pend_d[LK_PEND];
 };
 
+// Grid barrier over the G participating workgroups: every thread waits for its own (sc1) stores to be
+// acknowledged, lane 0 arrives on an agent-scope counter and polls the generation word.  No fence: all shared
+// data is accessed with sc1 loads / stores (see lk_ld / lk_st).
 __device__ __forceinline__ void lk_grid_barrier(LkShared* sh, int G) {
-  __threadfence();                      // every thread: its stores are visible device-wide
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int gen = __atomic_load_n(&sh->bar_gen, __ATOMIC_RELAXED);
-    if (atomicAdd(&sh->bar_count, 1) == G - 1) {
-      atomicExch(&sh->bar_count, 0);
-      __threadfence();
-      atomicAdd(&sh->bar_gen, 1);
+    const int gen = __hip_atomic_load(&sh->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(&sh->bar_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+      __hip_atomic_store(&sh->bar_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&sh->bar_gen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__atomic_load_n(&sh->bar_gen, __ATOMIC_RELAXED) == gen) __builtin_amdgcn_s_sleep(2);
+      while (__hip_atomic_load(&sh->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen)
+        __builtin_amdgcn_s_sleep(1);
     }
-    __threadfence();                    // acquire: drop this CU's stale L1 lines
   }
   __syncthreads();
 }
@@ -493,17 +514,17 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
 
   // ---- initialisation, split over the workgroups: sizes, ids, candidate bitmap, nearest neighbours
   for (int i = wg * LK_T + tid; i < n; i += G * LK_T) {
-    size[i] = 1;
-    cluster_id[i] = i;
+    lk_st(size + i, 1);
+    lk_st(cluster_id + i, i);
   }
-  for (int i = wg * LK_T + tid; i < cand_words; i += G * LK_T) cand[i] = 0u;
+  for (int i = wg * LK_T + tid; i < cand_words; i += G * LK_T) lk_st(cand + i, 0u);
   {
     const int lane = tid & 63, w = tid >> 6;
     for (int x = wg * LK_W + w; x < n - 1; x += G * LK_W) {
       MinPair best{__builtin_inf(), -1};
       const long base = (long)n * x - ((long)x * (x + 1) / 2) - x - 1;
       for (int i = x + 1 + lane; i < n; i += 64) {
-        const double d = D[base + i];
+        const double d = D[base + i];          // (written by k_pdist_f64, a previous kernel: plain load)
         if (d < best.d) {
           best.d = d;
           best.i = i;
@@ -517,15 +538,15 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
         best = min_pair(best, other);
       }
       if (lane == 0) {
-        nb[x] = best.i;
-        mind[x] = best.i < 0 ? __builtin_inf() : best.d;
+        lk_st(nb + x, best.i);
+        lk_st(mind + x, best.i < 0 ? __builtin_inf() : best.d);
       }
     }
   }
   lk_grid_barrier(sh, G);
   if (wg == 0) {
     for (int x = tid; x < hn; x += LK_T) {
-      heap.v[x] = mind[x];
+      heap.v[x] = lk_ld<true>(mind + x);
       heap.kbi[x] = (IT)x;
       heap.ibk[x] = (IT)x;
     }
@@ -545,11 +566,11 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
         if (tid == 0) {
           const int hx = heap.kbi[0];
           const double hd = heap.v[0];
-          const int hy = nb[hx];
+          const int hy = lk_ld<true>(nb + hx);
           sh_x = hx;
           sh_y = hy;
           sh_dist = hd;
-          sh_ok = (hy >= 0 && hd == D[cidx(n, hx, hy)]) ? 1 : 0;
+          sh_ok = (hy >= 0 && hd == lk_ld<true>(D + cidx(n, hx, hy))) ? 1 : 0;
         }
         __syncthreads();
         x = sh_x;
@@ -557,21 +578,21 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
         dist = sh_dist;
         const int ok = sh_ok;
         if (ok) break;
-        const MinPair p = block_find_min(D, size, n, x, red);
+        const MinPair p = block_find_min<true>(D, size, n, x, red);
         y = p.i;
         dist = p.d;
         if (tid == 0) {
-          nb[x] = y;
+          lk_st(nb + x, y);
           heap.change_value(x, dist);
-          mind[x] = dist;
+          lk_st(mind + x, dist);
           ++st_retry;
         }
         __syncthreads();
       }
       if (tid == 0) {
         heap.remove_min();
-        int id_x = cluster_id[x], id_y = cluster_id[y];
-        const int nx = size[x], ny = size[y];
+        int id_x = lk_ld<true>(cluster_id + x), id_y = lk_ld<true>(cluster_id + y);
+        const int nx = lk_ld<true>(size + x), ny = lk_ld<true>(size + y);
         if (id_x > id_y) {
           const int t = id_x;
           id_x = id_y;
@@ -581,15 +602,15 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
         Z[4 * (long)k + 1] = (double)id_y;
         Z[4 * (long)k + 2] = dist;
         Z[4 * (long)k + 3] = (double)(nx + ny);
-        size[x] = 0;
-        size[y] = nx + ny;
-        cluster_id[y] = n + k;
-        sh->x = x;
-        sh->y = y;
-        sh->nx = nx;
-        sh->ny = ny;
-        sh->dist = dist;
-        sh->npend = 0;
+        lk_st(size + x, 0);
+        lk_st(size + y, nx + ny);
+        lk_st(cluster_id + y, n + k);
+        lk_st(&sh->x, x);
+        lk_st(&sh->y, y);
+        lk_st(&sh->nx, nx);
+        lk_st(&sh->ny, ny);
+        lk_st(&sh->dist, dist);
+        lk_st(&sh->npend, 0);
       }
       const long long t2 = __builtin_readcyclecounter();
       st_c0 += t2 - tc;
@@ -601,8 +622,9 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
       st_c1 += t2 - tc;
       tc = t2;
     }
-    const int x = sh->x, y = sh->y, nx = sh->nx, ny = sh->ny;
-    const double dist = sh->dist;
+    const int x = lk_ld<true>(&sh->x), y = lk_ld<true>(&sh->y), nx = lk_ld<true>(&sh->nx),
+              ny = lk_ld<true>(&sh->ny);
+    const double dist = lk_ld<true>(&sh->dist);
     // ---- this workgroup's slices of the pass over all clusters z
     MinPair best{__builtin_inf(), -1};
     for (int z0 = wg * 4 * LK_T + tid; z0 < n; z0 += G * 4 * LK_T) {
@@ -612,10 +634,10 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int z = z0 + u * LK_T;
-        act[u] = z < n && z != y && size[z] != 0;
+        act[u] = z < n && z != y && lk_ld<true>(size + z) != 0;
         izy[u] = act[u] ? cidx(n, z, y) : 0;
-        d_xi[u] = act[u] ? D[cidx(n, z, x)] : 0.0;
-        d_yi[u] = act[u] ? D[izy[u]] : 0.0;
+        d_xi[u] = act[u] ? lk_ld<true>(D + cidx(n, z, x)) : 0.0;
+        d_yi[u] = act[u] ? lk_ld<true>(D + izy[u]) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -624,16 +646,16 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
         const double nd = sqrt(
             (((nx * d_xi[u] * d_xi[u]) + (ny * d_yi[u] * d_yi[u])) - ((nx * ny) * dist * dist) / (nx + ny)) /
             (nx + ny));
-        D[izy[u]] = nd;
+        lk_st(D + izy[u], nd);
         if (z < y) {
-          if (z < x && nb[z] == x) nb[z] = y;
-          if (nd < mind[z]) {
-            nb[z] = y;
+          if (z < x && lk_ld<true>(nb + z) == x) lk_st(nb + z, y);
+          if (nd < lk_ld<true>(mind + z)) {
+            lk_st(nb + z, y);
             atomicOr(&cand[z >> 5], 1u << (z & 31));
             const int slot = atomicAdd(&sh->npend, 1);
             if (slot < LK_PEND) {
-              sh->pend_z[slot] = z;
-              sh->pend_d[slot] = nd;
+              lk_st(&sh->pend_z[slot], z);
+              lk_st(&sh->pend_d[slot], nd);
             }
           }
         } else if (nd < best.d) {
@@ -655,7 +677,8 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
       MinPair r = red[0];
 #pragma unroll
       for (int q = 1; q < LK_W; ++q) r = min_pair(r, red[q]);
-      sh->red[wg] = r;
+      lk_st(&sh->red[wg].d, r.d);
+      lk_st(&sh->red[wg].i, r.i);
     }
     {
       const long long t2 = __builtin_readcyclecounter();
@@ -665,14 +688,14 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
     lk_grid_barrier(sh, G);
     if (wg == 0) {
       // ---- replay the heap updates in SciPy's order: ascending z < y, then row y
-      const int np = sh->npend;
+      const int np = lk_ld<true>(&sh->npend);
       if (np <= LK_PEND && tid < np) {
-        const int z = sh->pend_z[tid];
+        const int z = lk_ld<true>(&sh->pend_z[tid]);
         int rank = 0;
-        for (int q = 0; q < np; ++q) rank += sh->pend_z[q] < z ? 1 : 0;
+        for (int q = 0; q < np; ++q) rank += lk_ld<true>(&sh->pend_z[q]) < z ? 1 : 0;
         sort_z[rank] = z;
-        sort_d[rank] = sh->pend_d[tid];
-        cand[z >> 5] = 0u;
+        sort_d[rank] = lk_ld<true>(&sh->pend_d[tid]);
+        lk_st(cand + (z >> 5), 0u);
       }
       __syncthreads();
       if (tid == 0) {
@@ -680,32 +703,33 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
         if (np <= LK_PEND) {
           for (int q = 0; q < np; ++q) {
             heap.change_value(sort_z[q], sort_d[q]);
-            mind[sort_z[q]] = sort_d[q];
+            lk_st(mind + sort_z[q], sort_d[q]);
           }
         } else {
           ++st_ovf;
           const int words = (y + 31) / 32;
           for (int wi = 0; wi < words; ++wi) {
-            unsigned int m = cand[wi];
+            unsigned int m = lk_ld<true>(cand + wi);
             if (!m) continue;
-            cand[wi] = 0u;
+            lk_st(cand + wi, 0u);
             while (m) {
               const int bit = __builtin_ctz(m);
               m &= m - 1;
               const int z = wi * 32 + bit;
-              const double dz = D[cidx(n, z, y)];
+              const double dz = lk_ld<true>(D + cidx(n, z, y));
               heap.change_value(z, dz);
-              mind[z] = dz;
+              lk_st(mind + z, dz);
             }
           }
         }
         if (y < n - 1) {
-          MinPair r = sh->red[0];
-          for (int q = 1; q < G; ++q) r = min_pair(r, sh->red[q]);
+          MinPair r{lk_ld<true>(&sh->red[0].d), lk_ld<true>(&sh->red[0].i)};
+          for (int q = 1; q < G; ++q)
+            r = min_pair(r, MinPair{lk_ld<true>(&sh->red[q].d), lk_ld<true>(&sh->red[q].i)});
           if (r.i != -1) {
-            nb[y] = r.i;
+            lk_st(nb + y, r.i);
             heap.change_value(y, r.d);
-            mind[y] = r.d;
+            lk_st(mind + y, r.d);
           }
         }
       }
@@ -745,9 +769,11 @@ size_t pa_linkage_workspace_bytes(int n) {
 static int lk_num_workgroups(int n) {
   const char* e = getenv("PA_LINKAGE_WGS");
   if (e != nullptr && atoi(e) >= 1) return atoi(e) > 32 ? 32 : atoi(e);
-  if (n < 3000) return 1;                 // two grid barriers per merge cost more than the pass saves
-  const int g = n / 1800;
-  return g < 2 ? 2 : (g > 16 ? 16 : g);   // <= 16: two concurrent merges (two processes) still fit one XCD
+  // measured (profiles/r3_linkage_multi_workgroup.txt): the split pass wins only when the O(N) pass dominates
+  // the merge -- N = 57 k: 19.3 s -> 14.2 s with 16 workgroups; N = 20 k: no gain (the heap replay on workgroup
+  // 0, now on global-memory neighbour / min_dist arrays, costs what the pass saves).  16 workgroups: two
+  // concurrent merges (two processes on one GPU) still fit one XCD.
+  return n >= 30000 ? 16 : 1;
 }
 
 // D: condensed distance matrix (n*(n-1)/2 doubles), OVERWRITTEN.  Z: (n-1, 4) doubles, SciPy layout.
