@@ -118,9 +118,9 @@ def test_reference_inference_on_sample_wav(ref, model_dir, models):
 
 
 @pytest.mark.parametrize("seconds,seed,kwargs", [
-    (24.0, 3, {}),
-    (31.5, 8, {"num_speakers": 2}),
-    (27.0, 5, {"min_speakers": 2, "max_speakers": 3}),
+    (17.0, 3, {}),
+    (19.5, 8, {"num_speakers": 2}),
+    (16.0, 5, {"min_speakers": 2, "max_speakers": 3}),
 ])
 def test_reference_speaker_diarization_equals_oracle(ref, model_dir, models, seconds, seed, kwargs):
     """`SpeakerDiarization.apply` (pipelines/speaker_diarization.py:530-784) with the 3.1 configuration:
@@ -184,7 +184,7 @@ def test_reference_vbx_pipeline_equals_oracle(ref, model_dir, models):
     import oracle.vbx as ov
     from oracle.synthetic import synth_conversation
     seg_o, emb_o = models
-    conv, _ = synth_conversation(26.0, seed=11)
+    conv, _ = synth_conversation(17.0, seed=11)
     seen = {}
 
     def hook(name, artefact, file=None, **kw):
@@ -260,7 +260,7 @@ def test_reference_non_powerset_pipeline_equals_oracle(ref, tmp_path, models):
     ov.synth_plda(os.path.join(d, "plda"))
     params = {"clustering": AHC_PARAMS["clustering"], "segmentation": {"threshold": 0.5, "min_duration_off": 0.0}}
     pipe = _pipeline(ref, d, params=params)
-    conv, _ = synth_conversation(23.0, seed=14)
+    conv, _ = synth_conversation(16.0, seed=14)
     seen = {}
 
     def hook(name, artefact, file=None, **kw):
