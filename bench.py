@@ -343,14 +343,16 @@ def main():
     def run(num_files: int, tag: str, joint_mode: bool):
         """`num_files` steps = `num_files` one-hour files through the pipeline.  Per-file clustering:
         apply_batch, which overlaps clustering + reconstruction of file i with the front end of file i+1.
-        Joint: one apply_batch(joint_clustering=True) per step = front end of this rank's file, all-gather
-        of every rank's records over RCCL, one clustering of all of them, back end of this rank's file."""
+        Joint: one joint job per step = front end of this rank's file, all-gather of every rank's records
+        over RCCL, one clustering of all of them, back end of this rank's file; jobs pipelined through
+        `apply_joint_batches`."""
         files = [dict(file, uri=f"synthetic_{rank}_{tag}{i}") for i in range(num_files)]
         last = None
         if joint_mode:
-            for f in files:
-                for _, last in pipeline.apply_batch([f], joint_clustering=True):
-                    pass
+            # one joint job per step; consecutive jobs are pipelined (front ends + exchange of job i+1 beside
+            # the clustering / back end of job i), as apply_batch pipelines files
+            for outs in pipeline.apply_joint_batches([[f] for f in files]):
+                last = outs[-1][1]
         elif args.sequential:
             for f in files:
                 last = pipeline(f)

@@ -496,15 +496,48 @@ class SpeakerDiarization(Pipeline):
         """front end per file; records of all files of all ranks gathered on the device; ONE clustering
         over the concatenation along the chunk axis (oracle: the same clustering called on the
         concatenated arrays); back end for the local files."""
-        num_speakers, min_speakers, max_speakers = bounds
+        yield from self._joint_finish(self._joint_gather(files, hook, device), bounds)
+
+    def apply_joint_batches(self, groups: Iterable[Iterable[AudioFile]], num_speakers: Optional[int] = None,
+                            min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
+                            hook: Optional[Callable] = None) -> Iterator[List[Tuple[AudioFile, Any]]]:
+        """Several independent joint-clustering jobs (each `group` = the files of one
+        `apply_batch(group, joint_clustering=True)` call, BASELINE.json configs[4]) software-pipelined like
+        `apply_batch` pipelines files: the front ends and the record exchange of job i+1 run on the main
+        stream / thread (collectives stay in one thread, in the same order on every rank) while the joint
+        clustering and the back ends of job i run on a second stream.  Yields one [(file, output), ...] list
+        per job, in order; results are those of the sequential calls."""
+        bounds = self._speaker_bounds(num_speakers, min_speakers, max_speakers, {})
+        device = self._require_device()
+        side = torch.cuda.Stream(device=device)
+
+        def finish(job):
+            with torch.cuda.device(device), torch.cuda.stream(side):
+                out = list(self._joint_finish(job, bounds))
+                side.synchronize()
+            return out
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            in_flight = None
+            for group in groups:
+                job = self._joint_gather([Audio.validate_file(f) for f in group], hook, device)
+                if in_flight is not None:
+                    yield in_flight.result()
+                in_flight = pool.submit(finish, job)
+            if in_flight is not None:
+                yield in_flight.result()
+
+    def _joint_gather(self, files: List[dict], hook, device: torch.device) -> dict:
+        """first half of a joint job: front ends of the local files + the exchange of the per-chunk records of
+        all ranks (the only collectives of the path)"""
         hooks = [self.setup_hook(f, hook=hook) for f in files]
         fronts = [self._front_end(f, h) for f, h in zip(files, hooks)]
         voiced = [fr for fr in fronts if not fr.silent]
         shard = parallel.shard_from_env() if parallel.current_shard().world_size == 1 else parallel.Shard()
+        job = {"fronts": fronts, "hooks": hooks, "voiced": voiced, "empty": False}
         if not voiced and shard.world_size == 1:
-            for fr in fronts:
-                yield fr.file, self._empty_output(fr.file)
-            return
+            job["empty"] = True
+            return job
         F, S = (voiced[0].dev_seg.shape[1:] if voiced else (0, 0))
         D = self._embedding.dimension
         if shard.world_size > 1:
@@ -525,9 +558,20 @@ class SpeakerDiarization(Pipeline):
             segs = [fr.dev_seg for fr in voiced]
             embs = [fr.dev_emb for fr in voiced]
             mine = list(range(len(voiced)))
-        sizes = [s.shape[0] for s in segs]
-        all_seg = torch.cat(segs, dim=0).contiguous()
-        all_emb = torch.cat(embs, dim=0).cpu().numpy()
+        job.update(sizes=[s.shape[0] for s in segs], mine=mine,
+                   all_seg=torch.cat(segs, dim=0).contiguous(), all_emb=torch.cat(embs, dim=0).cpu().numpy())
+        torch.cuda.current_stream(device).synchronize()   # the second half may run on another stream
+        return job
+
+    def _joint_finish(self, job: dict, bounds):
+        """second half: ONE clustering over all records, then the back end of every local file"""
+        num_speakers, min_speakers, max_speakers = bounds
+        fronts, hooks = job["fronts"], job["hooks"]
+        if job["empty"]:
+            for fr in fronts:
+                yield fr.file, self._empty_output(fr.file)
+            return
+        all_seg, all_emb, sizes, mine = job["all_seg"], job["all_emb"], job["sizes"], job["mine"]
         _, clean = frame_ops.chunk_stats(all_seg)
         # the clustering only reads the SHAPE of the segmentations when the clean-frame counts are given
         seg_view = SlidingWindowFeature(all_seg.cpu().numpy(), self._chunk_grid())

@@ -117,6 +117,19 @@ def _free_port():
     return p
 
 
+def test_pipelined_joint_jobs_equal_sequential_calls(pipeline_dir, gpu_device):
+    """`apply_joint_batches`: independent joint-clustering jobs (configs[4], one job per bench step) pipelined --
+    front ends of job i+1 beside the clustering / back ends of job i -- give the outputs of the separate calls."""
+    import pyannote_audio_amd as pa
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir).to(gpu_device)
+    groups = [_files([(21.0, 5), (14.0, 3)]), _files([(18.5, 8)]), _files([(3.0, 21), (16.0, 2)])]
+    want = [[(f["uri"], _turns(o.speaker_diarization))
+             for f, o in pipeline.apply_batch(copy.copy(g), joint_clustering=True)] for g in groups]
+    got = [[(f["uri"], _turns(o.speaker_diarization)) for f, o in job]
+           for job in pipeline.apply_joint_batches(groups)]
+    assert got == want
+
+
 def _joint_worker(rank, world, port, pipeline_dir, specs, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
