@@ -18,9 +18,12 @@ class EmbeddingEngine:
 
     def __init__(self, pack: EmbeddingPack, max_chunks: Optional[int] = None):
         self.pack = pack
-        # chunks per launch group: ~31 MB of activations per 10 s chunk -> 8 GB at 256 (measured: 64 -> 256
-        # = +2.6 % throughput, fewer launches and tails; tuning aid: PA_EMB_BATCH)
-        self.max_chunks = max_chunks or int(os.environ.get("PA_EMB_BATCH", "256"))
+        # chunks per launch group: ~31 MB of activations per 10 s chunk -> 16 GB at 512 of the 288 GB.  Measured
+        # per audio-hour (profiles/r3_emb_batch_sweep.txt): 64 -> 1 131 ms, 128 -> 1 068, 256 -> 1 039,
+        # 512 -> 1 023: fewer launches and tails win; groups sized to the 256-MiB Infinity Cache (8 chunks, so that
+        # a convolution would read its predecessor's output on-die) are far on the wrong side of that trade.
+        # The chunks of a file are split EVENLY over the groups (3 591 = 8 x 449, not 7 x 512 + 7).
+        self.max_chunks = max_chunks or int(os.environ.get("PA_EMB_BATCH", "512"))
         self._ws = None
         self._idx_cache: dict = {}
 
@@ -63,8 +66,10 @@ class EmbeddingEngine:
             masks = masks.to(dev, torch.float32).contiguous()
         emb = torch.empty((num_chunks, S, w.embed_dim), dtype=torch.float32, device=dev)
         c0 = 0
+        groups = -(-num_chunks // self.max_chunks)
+        per_group = -(-num_chunks // groups)
         while c0 < num_chunks:
-            nb = min(self.max_chunks, num_chunks - c0)
+            nb = min(per_group, num_chunks - c0)
             ws = self._workspace(lib.pa_emb_workspace_bytes(w, nb, num_samples, S))
             off = c0 * chunk_stride
             sub = wav[off:]
