@@ -18,12 +18,14 @@ class EmbeddingEngine:
 
     def __init__(self, pack: EmbeddingPack, max_chunks: Optional[int] = None):
         self.pack = pack
-        # chunks per launch group: ~31 MB of activations per 10 s chunk -> 16 GB at 512 of the 288 GB.  Measured
+        # chunks per launch group: ~31 MB of activations per 10 s chunk -> 62 GB at 2 048 of the 288 GB.  Measured
         # per audio-hour (profiles/r3_emb_batch_sweep.txt): 64 -> 1 131 ms, 128 -> 1 068, 256 -> 1 039,
-        # 512 -> 1 023: fewer launches and tails win; groups sized to the 256-MiB Infinity Cache (8 chunks, so that
-        # a convolution would read its predecessor's output on-die) are far on the wrong side of that trade.
-        # The chunks of a file are split EVENLY over the groups (3 591 = 8 x 449, not 7 x 512 + 7).
-        self.max_chunks = max_chunks or int(os.environ.get("PA_EMB_BATCH", "512"))
+        # 512 -> 1 023 / 1 013 (split evenly), 1 024 -> 1 007, 2 048 -> 1 001, the whole file in one group (111 GB)
+        # -> 1 000: every launch pays a pipeline fill and a tail, so fewer and longer launches win (Winograd
+        # kernel 0.55 -> 0.62 of peak); groups sized to the 256-MiB Infinity Cache (8 chunks, so that a convolution
+        # would read its predecessor's output on-die) are far on the wrong side of that trade.  The chunks of a
+        # file are split EVENLY over the groups (3 591 = 2 x 1 796).
+        self.max_chunks = max_chunks or int(os.environ.get("PA_EMB_BATCH", "2048"))
         self._ws = None
         self._idx_cache: dict = {}
 

@@ -120,3 +120,23 @@ def test_soft_reconstruction_bit_exact(gpu_device):
                                       hard, cnt)
         got = rec.discretize().data
         assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_soft_reconstruction_full_hour(gpu_device):
+    """the soft (non-powerset) reconstruction at BASELINE configs[3] size: 3 591 chunks, 213 334 frames --
+    float32 overlap-add in chunk order + float top-k, bit-identical to the oracle's chunk / frame loops."""
+    from oracle import pipeline as op
+    rng = np.random.default_rng(9)
+    C, F, S = 3591, 589, 3
+    scores = rng.uniform(size=(C, F, S)).astype(np.float32)
+    hard = rng.integers(0, 4, size=(C, S))
+    hard[rng.uniform(size=(C, S)) < 0.15] = -2
+    chunks, frames = op.SW(0.0, 10.0, 1.0), op.SW(0.0, 991 / 16000, 270 / 16000)
+    count, cf = op.speaker_count((scores > 0.5).astype(np.float32), chunks, frames)
+    cnt = np.minimum(count, 2).astype(np.int8)
+    want = op.reconstruct(scores, chunks, hard.copy(), cnt, cf)
+    rec = frame_ops.Reconstructor(torch.from_numpy(scores).to(gpu_device),
+                                  SlidingWindow(start=0.0, duration=10.0, step=1.0),
+                                  SlidingWindow(start=0.0, duration=991 / 16000, step=270 / 16000), hard, cnt)
+    got = rec.discretize().data
+    assert got.shape == want.shape == (213334, 4) and np.array_equal(got, want)
