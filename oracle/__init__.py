@@ -9,7 +9,12 @@ embedding -> agglomerative clustering -> reconstruction).  It is the *checker*:
   * the product package (`pyannote-audio_amd/`, importable as `pyannote_audio_amd`)
     never imports it and has no CPU fallback: it raises when the HIP library is absent.
 
-Pinning status (see DESIGN.md "Oracle"):
+Pinning status: since round 3 the REFERENCE'S OWN CODE is executed against this
+package in the build container (tests/refharness.py loads it from /root/reference/src with stand-ins for the
+absent third-party packages): tests/test_oracle_vs_reference_files.py, tests/test_reference_pipeline.py -- the
+whole SpeakerDiarization.apply, the loaders, PyanNet, WeSpeaker ResNets, XVectorSincNet, SSeRiouSS, AHC / VBx
+clustering and binarize are bit-identical to the functions here.  What stays unpinned are the third-party
+stand-ins themselves:
 
   * torch `nn.LSTM / Conv1d / Conv2d / InstanceNorm1d / BatchNorm2d / MaxPool1d / Linear /
     LogSoftmax / F.interpolate` and scipy `linkage / fcluster / cdist` ARE the code the

@@ -1,23 +1,27 @@
 #!/bin/bash
-# round-end validation on the GPU box: full GPU suite, default bench line, smoke, rocprof kernel stats
+# round-end validation on the GPU box: full GPU suite, default bench line, smoke, N = 1 under torchrun (the
+# configs[4] code path with one rank), then tools/capture_profiles.sh (kernel stats + PMC passes at HEAD)
+# usage (via gpurun): bash tools/final_check.sh r3
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
-O=gpurun_out/final; mkdir -p $O
-R=$PWD
-timeout 240 python -m pytest tests -m gpu -x -q > $O/test_all.txt 2>&1
-tail -4 $O/test_all.txt
-timeout 80 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 30 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
+tag=${1:-r3}
+O=gpurun_out/final_$tag; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1
+tail -4 $O/gpu_tests.txt
+timeout 200 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 tail -2 $O/smoke.txt
-cd /tmp && timeout 60 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --sequential > $R/$O/bench_under_rocprof.json 2> $R/$O/stats.err; cd $R
-find /tmp/final_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-python - <<'PY'
+timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 \
+    bench.py --gpus 1 --steps 5 --no-cpu-baseline > $O/bench_torchrun_n1.json 2> $O/torchrun.err
+timeout 200 python bench.py --sequential --steps 3 --no-cpu-baseline > $O/bench_sequential.json 2>/dev/null
+timeout 700 sh tools/capture_profiles.sh $tag > $O/capture.log 2>&1
+python - <<PY
 import json
-for f in ("bench_default.json", "bench_under_rocprof.json"):
+for f in ("bench_default.json", "bench_torchrun_n1.json", "bench_sequential.json"):
     try:
-        d = json.loads(open("gpurun_out/final/" + f).read().strip().splitlines()[-1])
-        print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
+        d = json.loads(open("$O/" + f).read().strip().splitlines()[-1])
+        print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["roofline"]["traffic_source"])
     except Exception as e:
         print(f, "ERR", e)
 PY
-head -4 $O/kernel_stats.csv | cut -c1-160
+ls gpurun_out/prof_$tag
