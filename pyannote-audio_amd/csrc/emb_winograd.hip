@@ -16,7 +16,8 @@
 //     output channels of one tile for all 16 points: the inverse transform A^T M A is lane-local float4
 //     arithmetic (packed f32 adds; subtractions as v_pk_fma_f32 with an opaque -1) and the epilogue =
 //     + BN shift (+ residual) (+ ReLU) moves 16 bytes per access (8 stores + 8 residual loads per lane
-//     instead of 32 + 32), branch-free;
+//     instead of 32 + 32), branch-free; on the 8 x 32-pixel tiles half of the residual travels through LDS
+//     (LDS-DMA pieces issued in front of the tile's last MFMA run, which hides their latency: RPRE below);
 //   * staging is LDS-DMA (buffer_load_dwordx4 ... lds: global -> LDS without passing through VGPRs, the
 //     hardware bounds check zero-fills the halo): the input patch, de-interleaved by column parity so
 //     that the stride-2 tile walk reads consecutive LDS rows, and the U slab.  Rows are 64 B (16
@@ -55,6 +56,9 @@
 
 #ifndef PA_WINO_STAMP
 #define PA_WINO_STAMP 0
+#endif
+#ifndef PA_WINO_RPRE   // residual prefetch through LDS in front of a tile's last MFMA run (-DPA_WINO_RPRE=0: A/B)
+#define PA_WINO_RPRE 1
 #endif
 namespace pa {
 
@@ -241,12 +245,17 @@ __device__ __forceinline__ void wino_out_offsets(int (&off)[4], const WinoTile& 
 }
 
 // PRE: the residual values were loaded by the caller (inside the last MFMA run) into `rv`
-template <bool HAS_R, bool PRE = false>
+// PRE0: the first channel group's four residual vectors were sent to LDS (`rbuf`, 1 KB per wave and vector, lane l
+// at 16 l) by LDS-DMA pieces issued in front of the tile's LAST MFMA run, so that their HBM latency hides under
+// that run without holding registers (the kernel has none to spare: a register version spilled 20-30 VGPRs);
+// the second group's loads are issued here and hide under the first group's inverse transform.
+template <bool HAS_R, bool PRE = false, bool PRE0 = false>
 __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
                                               int COUT, const float* __restrict__ shift,
                                               const float* __restrict__ R, float* __restrict__ Y,
                                               int relu, int t, int g, int wr, int wc, float m1,
-                                              const int* off_pre = nullptr, f32x4 (*rv_pre)[4] = nullptr) {
+                                              const int* off_pre = nullptr, f32x4 (*rv_pre)[4] = nullptr,
+                                              const float* rbuf = nullptr) {
   const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
       Y + (long)q.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -260,11 +269,15 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
   }
   f32x4 rv[2][4];
 #pragma unroll
-  for (int cg = 0; cg < 2; ++cg)
+  for (int cgi = 0; cgi < 2; ++cgi)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      const int cg = (PRE0 && HAS_R) ? 1 - cgi : cgi;   // PRE0: the global loads of group 1 go out first
       if (PRE && HAS_R) rv[cg][e] = rv_pre[cg][e];
-      else
+      else if (PRE0 && HAS_R && cg == 0) {
+        if (e == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the 4 loads of cg = 1 are newer
+        rv[0][e] = *reinterpret_cast<const f32x4*>(rbuf + 256 * e);
+      } else
         rv[cg][e] = HAS_R ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off[e] + 64 * cg, 0, 0))
                           : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -308,6 +321,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   float* patch = smem;
   float* uslab = smem + G::PATCH;
 
+  // residual staging (RPRE): 4 x 1 KB per wave behind the mailbox, for the 8 x 32-pixel tiles of the 32- and
+  // 64-channel layers (few stages per tile: the residual's latency was 14 % / 8 % of a tile).  Measured per
+  // launch (B = 512, profiles/r3_wino_residual_prefetch.txt): 80x998x32 4.91 -> 4.44 ms, 40x499x64 3.77 -> 3.55;
+  // on the 4 x 64-pixel tiles (128 channels) it LOSES 1 % and the 2 x 128-pixel tiles have no LDS left for it.
+  constexpr bool RPRE = PA_WINO_RPRE && HAS_R && TCG == 1;
+  float* rbuf = smem + G::LDS_FLOATS + 4 + 1024 * slw;
   // tiles are CLAIMED, not statically strided (common.h: TileQueue): thread 0 claims the next tile while
   // the current one is processed and publishes it through LDS at the tile boundary
   int* s_next = reinterpret_cast<int*>(smem + G::LDS_FLOATS);
@@ -348,6 +367,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
         asm volatile("s_nop 0" ::"v"(v[3][3]), "v"(v[0][0]));   // the transform is complete here
 #endif
         WINO_STAMP(5);
+        if (RPRE && c0 + WCB >= CIN) {
+          // last stage of the tile: the residual vectors of the first channel group leave for LDS now, ahead
+          // of the MFMA run that hides their latency (wino_epilogue<.., PRE0>)
+          int off_pre[4];
+          wino_out_offsets(off_pre, cur, W, COUT, t, g, wr, wc);
+          const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<float*>(R + (long)cur.b * H * W * COUT), 0, H * W * COUT * 4, 0x00020000);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrd, (lds_ptr_t)(rbuf + 256 * e), 16, off_pre[e], 0, 0, 0);
+        }
         if (c0 == 0) wino_mfma<true>(uslab, v, acc, t, g);
         else wino_mfma<false>(uslab, v, acc, t, g);
         WINO_STAMP(6);
@@ -356,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
           WINO_STAMP_FLUSH();
         }
       }
-      wino_epilogue<HAS_R>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1);
+      wino_epilogue<HAS_R, false, RPRE>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1, nullptr, nullptr,
+                                        rbuf + 4 * lane);
       WINO_STAMP(7);
       WINO_STAMP_FLUSH();
       if (tid == 0) *s_next = tq_resolve(tq, ahead);
@@ -372,7 +403,9 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
                          const float* R, float* Y, int COUT, int relu, hipStream_t st) {
   using G = WinoGeom<TR, TCG>;
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
-  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + 16;   // + the claimed-tile mailbox
+  // + the claimed-tile mailbox (+ 16 KB of residual staging where it is used: k_conv3x3_wino RPRE)
+  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + 16 +
+                     ((PA_WINO_RPRE && HAS_R && TCG == 1) ? 4 * 4096 : 0);
   auto kernel = k_conv3x3_wino<TR, TCG, HAS_R>;
   // per-device launch state (the attribute and the CU count belong to a device, not to the process)
   constexpr int MAXDEV = 16;
