@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
           WINO_STAMP_FLUSH();
         }
       }
+      // (Issuing the NEXT tile's first stage in front of this epilogue, so that the epilogue hides its flight
+      // time, was measured 3-8 % SLOWER on every layer shape: profiles/r3_wino_next_tile_prefetch.txt -- the
+      // extra DMA issue lands in the phase where the other workgroup's MFMA stream owns the SIMD.)
       wino_epilogue<HAS_R, false, RPRE>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1, nullptr, nullptr,
                                         rbuf + 4 * lane);
       WINO_STAMP(7);
