@@ -143,6 +143,11 @@ def _joint_worker(rank, world, port, pipeline_dir, specs, q):
     mine = _files(specs[rank])
     res = [(f["uri"], _turns(o.speaker_diarization), o.speaker_embeddings.tolist())
            for f, o in pipeline.apply_batch(mine, joint_clustering=True)]
+    # the same job twice through the pipelined form (what bench.py --gpus N runs): collectives stay in the main
+    # thread, in the same order on every rank; the clustering / back ends run in the worker thread
+    again = [[(f["uri"], _turns(o.speaker_diarization)) for f, o in job]
+             for job in pipeline.apply_joint_batches([_files(specs[rank]), _files(specs[rank])])]
+    assert again[0] == again[1] == [(u, t) for u, t, _ in res]
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
