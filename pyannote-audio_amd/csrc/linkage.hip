@@ -769,11 +769,12 @@ size_t pa_linkage_workspace_bytes(int n) {
 static int lk_num_workgroups(int n) {
   const char* e = getenv("PA_LINKAGE_WGS");
   if (e != nullptr && atoi(e) >= 1) return atoi(e) > 32 ? 32 : atoi(e);
-  // measured (profiles/r3_linkage_multi_workgroup.txt): the split pass wins only when the O(N) pass dominates
-  // the merge -- N = 57 k: 19.3 s -> 14.2 s with 16 workgroups; N = 20 k: no gain (the heap replay on workgroup
-  // 0, now on global-memory neighbour / min_dist arrays, costs what the pass saves).  16 workgroups: two
-  // concurrent merges (two processes on one GPU) still fit one XCD.
-  return n >= 30000 ? 16 : 1;
+  // measured: the split pass wins when the O(N) pass dominates the merge.  On the joint clustering of REAL
+  // embeddings (profiles/r3_joint_scale.txt) 16 workgroups take 0.92 -> 0.78 s at N = 14 k (8 workgroups: 0.72 s),
+  // 3.59 -> 2.02 s at 29 k, 14.2 -> 6.7 s at 57 k; on the 4-blob synthetic set of tools/time_linkage.py, which needs
+  // 10x as many heap updates per merge, only the largest size gains (profiles/r3_linkage_multi_workgroup.txt).
+  // <= 16 workgroups: two concurrent merges (two processes on one GPU) still fit one XCD.
+  return n >= 20000 ? 16 : (n >= 12000 ? 8 : 1);
 }
 
 // D: condensed distance matrix (n*(n-1)/2 doubles), OVERWRITTEN.  Z: (n-1, 4) doubles, SciPy layout.
