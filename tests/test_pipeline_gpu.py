@@ -125,6 +125,28 @@ def test_linkage_centroid_bit_exact_vs_scipy(gpu_device, n, d, dup, seed):
     assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
 
 
+@pytest.mark.parametrize("n,workgroups", [(12300, None), (3000, 4), (12300, 1)])
+def test_linkage_multi_workgroup_vs_scipy(gpu_device, n, workgroups, monkeypatch):
+    """the multi-workgroup merge (k_linkage_centroid_mw: O(N) pass split over the workgroups of one XCD, heap
+    replay on workgroup 0, sc1 accesses instead of fences) in its LDS-heap range -- N = 12 300 picks 8
+    workgroups by itself; a forced 4-workgroup run on a small problem; the single-workgroup kernel at the same
+    size -- bit-identical to SciPy, exact ties included."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+    from pyannote_audio_amd import distance
+    if workgroups is not None:
+        monkeypatch.setenv("PA_LINKAGE_WGS", str(workgroups))
+    rng = np.random.default_rng(n)
+    centers = rng.standard_normal((4, 32))
+    X = (centers[rng.integers(0, 4, n)] + 0.5 * rng.standard_normal((n, 32))).astype(np.float32)
+    X[rng.integers(0, n, 60)] = X[rng.integers(0, n, 60)]
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    want = linkage(pdist(X), method="centroid")
+    got = distance.linkage_centroid(X, gpu_device)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
+
+
 def test_non_powerset_pipeline_matches_oracle(synthetic_models, gpu_device, tmp_path):
     """a14: a multi-label segmentation checkpoint -- sigmoid scores out of the
     classifier kernel, hysteresis thresholding (pipelines/speaker_diarization.py:599-606, utils/signal.py:
