@@ -93,9 +93,9 @@ def test_conv3x3_configs(gpu_device):
                                  ffi.ptr(rd) if use_res else None, ffi.ptr(y), cout, s, 1, ffi.stream()),
                   "conv3x3")
         torch.cuda.synchronize()
-        e = report(f"conv3x3_{cin}_{cout}_{H}x{W}_s{s}_B{B}", y.permute(0, 3, 1, 2), ref)
         assert not torch.isnan(y).any()
-        assert e < 1e-4 * ref.abs().max().item()
+        # element-wise north_star contract (rtol 1e-4 / atol 1e-5), also for this intermediate activation
+        assert north_star_ratio(f"conv3x3_{cin}_{cout}_{H}x{W}_s{s}_B{B}", y.permute(0, 3, 1, 2), ref) <= 1.0
 
 
 def test_stats_pool_kats(gpu_device):
@@ -184,8 +184,7 @@ def test_conv3x3_winograd(gpu_device):
                   "conv3x3_wino")
         torch.cuda.synchronize()
         assert not torch.isnan(y).any(), (cin, cout, H, W, B)
-        e = report(f"wino3x3_{cin}_{cout}_{H}x{W}_B{B}", y.permute(0, 3, 1, 2), ref)
-        assert e < 1e-4 * ref.abs().max().item()
+        assert north_star_ratio(f"wino3x3_{cin}_{cout}_{H}x{W}_B{B}", y.permute(0, 3, 1, 2), ref) <= 1.0
 
 
 @pytest.mark.parametrize("num_blocks", [(1, 1, 1, 1), (2, 3, 2, 2)])

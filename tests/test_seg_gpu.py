@@ -62,24 +62,21 @@ def test_frontend_stages(seg, gpu_device):
     s1 = torch.zeros(B, 80, P1, device=dev)
     ffi.check(lib.pa_sinc_fir_pool(ffi.ptr(xd), xd.numel(), N, B, N, 10, ffi.ptr(mean), ffi.ptr(rstd),
                                    w.wav_gamma, w.wav_beta, w.sinc_filt, ffi.ptr(s1), st))
-    e = report("sinc_pool", s1, p1)
-    assert e < 1e-4 * p1.abs().max().item() + 1e-5
+    assert north_star_ratio("sinc_pool", s1, p1) <= 1.0       # element-wise rtol 1e-4 / atol 1e-5
     m1 = torch.empty(B * 80, device=dev); r1 = torch.empty(B * 80, device=dev)
     ffi.check(lib.pa_row_stats(ffi.ptr(s1), P1, s1.numel(), B * 80, P1, 1e-5, ffi.ptr(m1), ffi.ptr(r1), st))
     P2 = p2.shape[-1]
     s2 = torch.zeros(B, 60, P2, device=dev)
     ffi.check(lib.pa_conv5_pool(ffi.ptr(s1), B, 80, P1, ffi.ptr(m1), ffi.ptr(r1), w.norm0,
                                 C.c_void_p(w.norm0 + 80 * 4), w.conv1_w, w.conv1_b, ffi.ptr(s2), st))
-    e = report("conv1_pool", s2, p2)
-    assert e < 1e-4 * p2.abs().max().item() + 1e-5
+    assert north_star_ratio("conv1_pool", s2, p2) <= 1.0
     m2 = torch.empty(B * 60, device=dev); r2 = torch.empty(B * 60, device=dev)
     ffi.check(lib.pa_row_stats(ffi.ptr(s2), P2, s2.numel(), B * 60, P2, 1e-5, ffi.ptr(m2), ffi.ptr(r2), st))
     T = p3.shape[-1]
     s3 = torch.zeros(B, 60, T, device=dev)
     ffi.check(lib.pa_conv5_pool(ffi.ptr(s2), B, 60, P2, ffi.ptr(m2), ffi.ptr(r2), w.norm1,
                                 C.c_void_p(w.norm1 + 60 * 4), w.conv2_w, w.conv2_b, ffi.ptr(s3), st))
-    e = report("conv2_pool", s3, p3)
-    assert e < 1e-4 * p3.abs().max().item() + 1e-5
+    assert north_star_ratio("conv2_pool", s3, p3) <= 1.0
     m3 = torch.empty(B * 60, device=dev); r3 = torch.empty(B * 60, device=dev)
     ffi.check(lib.pa_row_stats(ffi.ptr(s3), T, s3.numel(), B * 60, T, 1e-5, ffi.ptr(m3), ffi.ptr(r3), st))
     X0 = torch.full((1 * T * 16, 64), float("nan"), device=dev)
@@ -87,8 +84,7 @@ def test_frontend_stages(seg, gpu_device):
                                     C.c_void_p(w.norm2 + 60 * 4), ffi.ptr(X0), st))
     torch.cuda.synchronize()
     X0 = X0.view(T, 16, 64).cpu()
-    e = report("sincnet_out", X0[:, :B, :60].permute(1, 2, 0), a3)
-    assert e < 2e-4
+    assert north_star_ratio("sincnet_out", X0[:, :B, :60].permute(1, 2, 0), a3) <= 1.0
     assert torch.all(X0[:, B:] == 0) and torch.all(X0[:, :, 60:] == 0)
 
 
@@ -112,8 +108,11 @@ def test_gemm_tn(gpu_device):
             got = got.view(M // 16, N, 16).permute(0, 2, 1).reshape(M, N)
         else:
             got = got.view(M, N)
-        e = report(f"gemm_{M}x{N}x{K}", got, ref)
-        assert e < 1e-4 * ref.abs().max().item()
+        if K <= 256:      # element-wise contract against the float64 product
+            assert north_star_ratio(f"gemm_{M}x{N}x{K}", got, ref) <= 1.0
+        else:             # K = 5 120 random terms: float32 summation itself is only good to ~1e-5 absolute here
+            e = report(f"gemm_{M}x{N}x{K}", got, ref)
+            assert e < 1e-4 * ref.abs().max().item()
 
 
 def test_lstm_layer(seg, gpu_device):
@@ -145,8 +144,7 @@ def test_lstm_layer(seg, gpu_device):
               "lstm")
     torch.cuda.synchronize()
     got = out.view(ntiles, T, 16, 256).permute(0, 2, 1, 3).reshape(ntiles * 16, T, 256)[:B].cpu()
-    e = report("lstm_layer0", got, ref)
-    assert e < 1e-4
+    assert north_star_ratio("lstm_layer0", got, ref) <= 1.0
 
 
 @pytest.mark.parametrize("B,N,stride", [(5, 80000, 8000), (18, 160000, 16000)])
