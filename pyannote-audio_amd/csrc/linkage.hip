@@ -131,19 +131,14 @@ __device__ MinPair block_find_min(const double* __restrict__ D, const int* __res
   const long base = (long)n * x - ((long)x * (x + 1) / 2) - x - 1;  // cidx(n, x, i) = base + i
   for (int i0 = x + 1 + threadIdx.x; i0 < n; i0 += 4 * LK_T) {
     // 4 row elements per thread in flight (ascending i, so the strict `<` keeps the first minimum)
-    // the distance does not wait for the size: both loads go out together (an inactive column's entry is
-    // stale but readable) -- the dependent pair cost a second memory round trip per row scan
     double d[4];
     bool act[4];
-    int sz[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * LK_T;
-      sz[u] = i < n ? lk_ld<COH>(size + i) : 0;
-      d[u] = i < n ? lk_ld<COH>(D + base + i) : 0.0;
+      act[u] = i < n && lk_ld<COH>(size + i) != 0;
+      d[u] = act[u] ? lk_ld<COH>(D + base + i) : 0.0;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) act[u] = sz[u] != 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (act[u] && d[u] < best.d) {
@@ -261,40 +256,31 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
     double dist = 0.0;
     long long tc = __builtin_readcyclecounter();
     for (int it = 0; it < n - k; ++it) {
-      // The candidate at the top of the heap is checked against the matrix by lane 0 WHILE the whole block
-      // already scans its row: 9 merges out of 10 need that scan (the lower bound is stale), so speculating it
-      // takes the check's memory round trip and one barrier out of every iteration.  Same heap operations in
-      // the same order as SciPy's loop.
-      if (tid == 0) sh_x = heap.kbi[0];
+      if (tid == 0) {
+        const int hx = heap.kbi[0];
+        const double hd = heap.v[0];
+        const IT hyr = nb[hx];
+        const int hy = hyr == NONE ? -1 : (int)hyr;
+        sh_x = hx;
+        sh_y = hy;
+        sh_dist = hd;
+        sh_ok = (hy >= 0 && hd == D[cidx(n, hx, hy)]) ? 1 : 0;
+      }
       __syncthreads();
       x = sh_x;
-      int hy = -1;
-      double hd = 0.0, dchk = 0.0;
-      if (tid == 0) {
-        hd = heap.v[0];
-        const IT hyr = nb[x];
-        hy = hyr == NONE ? -1 : (int)hyr;
-        if (hy >= 0) dchk = D[cidx(n, x, hy)];   // in flight during the scan
-      }
-      const MinPair p = block_find_min(D, size, n, x, red);  // (barriers inside)
-      if (tid == 0) {
-        const int ok = (hy >= 0 && hd == dchk) ? 1 : 0;
-        sh_ok = ok;
-        if (ok) {
-          sh_y = hy;
-          sh_dist = hd;
-        } else {
-          sh_y = p.i;
-          sh_dist = p.d;
-          nb[x] = p.i < 0 ? NONE : (IT)p.i;
-          heap.change_value(x, p.d);
-          ++st_retry;
-        }
-      }
-      __syncthreads();
       y = sh_y;
       dist = sh_dist;
-      if (sh_ok) break;
+      const int ok = sh_ok;
+      if (ok) break;
+      const MinPair p = block_find_min(D, size, n, x, red);  // (barriers inside)
+      y = p.i;
+      dist = p.d;
+      if (tid == 0) {
+        nb[x] = y < 0 ? NONE : (IT)y;
+        heap.change_value(x, dist);
+        ++st_retry;
+      }
+      __syncthreads();
     }
     {
       const long long t2 = __builtin_readcyclecounter();
@@ -334,23 +320,17 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
     MinPair best{__builtin_inf(), -1};
     for (int z0 = tid; z0 < n; z0 += 4 * LK_T) {
       // 4 clusters per thread: all 8 distance loads are issued before the first use
-      // sizes and both distances are loaded TOGETHER (an inactive cluster's entries are stale but readable):
-      // waiting for size[z] before addressing D cost a second memory round trip in every merge
       bool act[4];
       long izy[4];
-      int sz[4];
       double d_xi[4], d_yi[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int z = z0 + u * LK_T;
-        const bool ok = z < n && z != y && z != x;
-        sz[u] = ok ? size[z] : 0;
-        izy[u] = ok ? cidx(n, z, y) : 0;
-        d_xi[u] = ok ? D[cidx(n, z, x)] : 0.0;
-        d_yi[u] = ok ? D[izy[u]] : 0.0;
+        act[u] = z < n && z != y && size[z] != 0;
+        izy[u] = act[u] ? cidx(n, z, y) : 0;
+        d_xi[u] = act[u] ? D[cidx(n, z, x)] : 0.0;
+        d_yi[u] = act[u] ? D[izy[u]] : 0.0;
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) act[u] = sz[u] != 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (!act[u]) continue;
@@ -583,38 +563,31 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
       int x = 0, y = 0;
       double dist = 0.0;
       for (int it = 0; it < n - k; ++it) {
-        // lane 0 checks the heap's candidate against the matrix while the block already scans its row
-        // (speculation, as in k_linkage_centroid)
-        if (tid == 0) sh_x = heap.kbi[0];
+        if (tid == 0) {
+          const int hx = heap.kbi[0];
+          const double hd = heap.v[0];
+          const int hy = lk_ld<true>(nb + hx);
+          sh_x = hx;
+          sh_y = hy;
+          sh_dist = hd;
+          sh_ok = (hy >= 0 && hd == lk_ld<true>(D + cidx(n, hx, hy))) ? 1 : 0;
+        }
         __syncthreads();
         x = sh_x;
-        int hy = -1;
-        double hd = 0.0, dchk = 0.0;
-        if (tid == 0) {
-          hd = heap.v[0];
-          hy = lk_ld<true>(nb + x);
-          if (hy >= 0) dchk = lk_ld<true>(D + cidx(n, x, hy));
-        }
-        const MinPair p = block_find_min<true>(D, size, n, x, red);
-        if (tid == 0) {
-          const int ok = (hy >= 0 && hd == dchk) ? 1 : 0;
-          sh_ok = ok;
-          if (ok) {
-            sh_y = hy;
-            sh_dist = hd;
-          } else {
-            sh_y = p.i;
-            sh_dist = p.d;
-            lk_st(nb + x, p.i);
-            heap.change_value(x, p.d);
-            lk_st(mind + x, p.d);
-            ++st_retry;
-          }
-        }
-        __syncthreads();
         y = sh_y;
         dist = sh_dist;
-        if (sh_ok) break;
+        const int ok = sh_ok;
+        if (ok) break;
+        const MinPair p = block_find_min<true>(D, size, n, x, red);
+        y = p.i;
+        dist = p.d;
+        if (tid == 0) {
+          lk_st(nb + x, y);
+          heap.change_value(x, dist);
+          lk_st(mind + x, dist);
+          ++st_retry;
+        }
+        __syncthreads();
       }
       if (tid == 0) {
         heap.remove_min();
@@ -655,26 +628,17 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
     // ---- this workgroup's slices of the pass over all clusters z
     MinPair best{__builtin_inf(), -1};
     for (int z0 = wg * 4 * LK_T + tid; z0 < n; z0 += G * 4 * LK_T) {
-      // everything a cluster's update needs is loaded TOGETHER, before the first use: size, both distances, and
-      // for z < y the neighbour candidate and the lower bound (five independent L2 round trips instead of four
-      // dependent ones; an inactive cluster's entries are stale but readable)
       bool act[4];
       long izy[4];
-      int sz[4], nbz[4];
-      double d_xi[4], d_yi[4], mz[4];
+      double d_xi[4], d_yi[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int z = z0 + u * LK_T;
-        const bool ok = z < n && z != y && z != x;
-        sz[u] = ok ? lk_ld<true>(size + z) : 0;
-        izy[u] = ok ? cidx(n, z, y) : 0;
-        d_xi[u] = ok ? lk_ld<true>(D + cidx(n, z, x)) : 0.0;
-        d_yi[u] = ok ? lk_ld<true>(D + izy[u]) : 0.0;
-        nbz[u] = (ok && z < y) ? lk_ld<true>(nb + z) : -1;
-        mz[u] = (ok && z < y) ? lk_ld<true>(mind + z) : 0.0;
+        act[u] = z < n && z != y && lk_ld<true>(size + z) != 0;
+        izy[u] = act[u] ? cidx(n, z, y) : 0;
+        d_xi[u] = act[u] ? lk_ld<true>(D + cidx(n, z, x)) : 0.0;
+        d_yi[u] = act[u] ? lk_ld<true>(D + izy[u]) : 0.0;
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) act[u] = sz[u] != 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (!act[u]) continue;
@@ -684,8 +648,8 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
             (nx + ny));
         lk_st(D + izy[u], nd);
         if (z < y) {
-          if (z < x && nbz[u] == x) lk_st(nb + z, y);
-          if (nd < mz[u]) {
+          if (z < x && lk_ld<true>(nb + z) == x) lk_st(nb + z, y);
+          if (nd < lk_ld<true>(mind + z)) {
             lk_st(nb + z, y);
             atomicOr(&cand[z >> 5], 1u << (z & 31));
             const int slot = atomicAdd(&sh->npend, 1);
