@@ -146,11 +146,37 @@ __device__ __forceinline__ f32x4 vsub(const f32x4 a, const f32x4 b, const float 
 }
 
 // input transform V = B^T d B of tile (wr, 16*wc + t) for channels 4g..4g+3, in registers
-template <int TR, int TCG>
+// PIPE: patch row i+1 is read while row i is combined (two register sets of 4 x f32x4) -- hipcc, short of
+// registers, otherwise waits for every group of four reads before it issues the next one.  Measured per launch
+// (profiles/r3_wino_transform_pipelined.txt): -0.5 ... -3.3 % on the launches without a residual input, +4 ... 6 %
+// (spills) on those with one, so the kernel asks for it only when HAS_R is false.
+template <int TR, int TCG, bool PIPE = false>
 __device__ __forceinline__ void wino_transform(const float* patch, const int (&pbase)[8], f32x4 (&v)[4][4],
                                                float m1) {
   using G = WinoGeom<TR, TCG>;
   const char* base = reinterpret_cast<const char*>(patch);
+  if (PIPE) {
+  f32x4 d[2][4];
+  auto rd = [&](int i, f32x4 (&o)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int K = (2 * i + (j & 1)) * G::PWH + (j >> 1);
+      o[j] = *reinterpret_cast<const f32x4*>(base + pbase[K & 7] + (K & ~7) * (WCB * 4));
+    }
+  };
+  rd(0, d[0]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i + 1 < 4) rd(i + 1, d[(i + 1) & 1]);
+    WINO_SCHED_BARRIER();
+    const f32x4(&c)[4] = d[i & 1];
+    v[i][0] = vsub(c[0], c[2], m1);
+    v[i][1] = c[1] + c[2];
+    v[i][2] = vsub(c[2], c[1], m1);
+    v[i][3] = vsub(c[1], c[3], m1);
+    WINO_SCHED_BARRIER();
+  }
+  } else {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x4 d[4];
@@ -163,6 +189,7 @@ __device__ __forceinline__ void wino_transform(const float* patch, const int (&p
     v[i][1] = d[1] + d[2];
     v[i][2] = vsub(d[2], d[1], m1);
     v[i][3] = vsub(d[1], d[3], m1);
+  }
   }
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) {
@@ -362,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
         wino_barrier();
         WINO_STAMP(4);
         f32x4 v[4][4];
-        wino_transform<TR, TCG>(patch, pbase, v, m1);
+        wino_transform<TR, TCG, !HAS_R>(patch, pbase, v, m1);
 #if PA_WINO_STAMP
         asm volatile("s_nop 0" ::"v"(v[3][3]), "v"(v[0][0]));   // the transform is complete here
 #endif
