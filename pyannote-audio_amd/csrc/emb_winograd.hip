@@ -57,6 +57,8 @@
 #ifndef PA_WINO_STAMP
 #define PA_WINO_STAMP 0
 #endif
+// (nt / "streaming" cache-policy bits on the patch DMA, the residual loads or the stores: measured neutral to
+//  10-25 % slower, profiles/r3_wino_cache_policy.txt -- every access keeps the default policy)
 #ifndef PA_WINO_RPRE   // residual prefetch through LDS in front of a tile's last MFMA run (-DPA_WINO_RPRE=0: A/B)
 #define PA_WINO_RPRE 1
 #endif
