@@ -46,6 +46,8 @@
 //     epilogue are all exposed.  Two workgroups per CU stay.
 // Numerics: fp32 throughout; the transforms only add/subtract and the 1/2 factors of G are applied in
 // float64 on the host; error ~3x the direct form's (tests: |err| <= 1e-4 max|ref| per conv, end to end).
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifdef PA_WINO_NOSCHED   // development A/B switch (never defined in the product build)
@@ -472,6 +474,147 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   return 0;
 }
 
+// =============================================================================================
+// CIN = COUT = 32 (layer 1 of the ResNet: 6 of the 29 Winograd launches, a quarter of their time).  With only two
+// channel stages per tile the generic kernel spends as long in DMA issue / waits / barriers / epilogue as in its
+// MFMA runs (0.49-0.52 of peak against 0.69-0.74 on the deeper layers).  Here
+//   * both U slabs (64 KB) are loaded ONCE per workgroup and stay in LDS: no weight DMA per tile at all;
+//   * a workgroup has 8 waves = two HALVES of 4 waves, each with its own 8 x 32-pixel tile and a patch buffer
+//     for BOTH channel stages (2 x 22 KB), staged by one DMA phase per tile;
+//   * the halves alternate: while one runs its two transform + MFMA stages back to back (no DMA, no barrier
+//     inside), the other does the epilogue of its previous tile -- the residual loads' and the stores' latency
+//     hide under the partner's MFMA run by construction -- and stages the patch of its next tile.
+//     Two workgroup barriers per pair of tiles.
+//   * tiles are claimed per half (TileQueue); the claim is issued in a PREPARE step, resolved in the next
+//     COMPUTE step and published by that step's closing barrier.
+// One workgroup per CU (152 KB of LDS), two waves per SIMD as before.
+// =============================================================================================
+template <bool HAS_R>
+__global__ __launch_bounds__(512) void k_conv3x3_wino32(
+    const float* __restrict__ X, int H, int W, const float* __restrict__ U, const float* __restrict__ shift,
+    const float* __restrict__ R, float* __restrict__ Y, int relu, int tiles_w, int tiles_hw, int total_tiles,
+    int num_pb, int* __restrict__ counters) {
+  using G = WinoGeom<4, 1>;
+  constexpr int CIN = 32, COUT = 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int half = __builtin_amdgcn_readfirstlane(wv >> 2);
+  const int slw = __builtin_amdgcn_readfirstlane(wv & 3);
+  const int wr = slw, wc = 0;
+  float* uslab = smem;                                           // [2 stages][USLAB]
+  float* patch = smem + 2 * G::USLAB + half * 2 * G::PATCH;      // [2 stages][PATCH] of this half
+  int* mail = reinterpret_cast<int*>(smem + 2 * G::USLAB + 4 * G::PATCH);   // [0..1] next tile, [2..3] alive
+  const bool leader = (tid & 255) == 0;
+
+  // the two U slabs: 64 pieces of 1 KB, 8 per wave, contiguous in the packed weight image
+  {
+    const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(U), 0, 16 * COUT * CIN * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = wv + 8 * i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (lds_ptr_t)(uslab + 256 * k), 16, lane * 16, 256 * k * 4, 0, 0);
+    }
+  }
+  const TileQueue tq{counters, (int)(blockIdx.x & 7), total_tiles >> 3};
+  if (leader) {
+    mail[half] = tq_resolve(tq, tq_claim_own(tq));
+    mail[2 + half] = 1;
+  }
+  const int x0_last = (tiles_w - 1) * 32;
+  int prel[G::NPP];
+  wino_patch_lanes<4, 1>(prel, W, CIN, lane, slw, x0_last);
+  int pbase[8];
+  wino_patch_bases<4, 1>(pbase, t, g, wr, wc);
+  const float m1 = wino_minus_one();
+  f32x4 acc[16][2];
+  __syncthreads();
+  int q = mail[half];          // tile being staged / computed by this half (-1: none left)
+  int done_q = -1;             // tile whose accumulators are waiting for their epilogue
+  int ahead = 0;
+  WinoTile cur = wino_decode(q < 0 ? 0 : q, tiles_w, tiles_hw, 1, 8, 32, num_pb), fin = cur;
+  if (q >= 0) {
+    wino_issue_patch<4, 1>(X, H, W, CIN, cur, 0, patch, prel, slw, x0_last);
+    wino_issue_patch<4, 1>(X, H, W, CIN, cur, WCB, patch + G::PATCH, prel, slw, x0_last);
+    if (leader) ahead = tq_claim_own(tq);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  wino_barrier();
+  // step s: half h COMPUTES when (s - h) is even and >= 0, otherwise it PREPARES
+  for (int step = 0;; ++step) {
+    const bool compute = step >= half && ((step - half) & 1) == 0;
+    if (compute) {
+      if (q >= 0) {
+        if (leader) mail[half] = tq_resolve(tq, ahead);   // the claim was issued a step ago: no round trip here
+#pragma unroll
+        for (int stage = 0; stage < 2; ++stage) {
+          f32x4 v[4][4];
+          wino_transform<4, 1, !HAS_R>(patch + stage * G::PATCH, pbase, v, m1);
+          if (stage == 0) wino_mfma<true>(uslab, v, acc, t, g);
+          else wino_mfma<false>(uslab + G::USLAB, v, acc, t, g);
+        }
+        done_q = q;
+        fin = cur;
+      } else if (leader) {
+        mail[2 + half] = 0;     // nothing left for this half (its last epilogue ran in the previous step)
+      }
+    } else if (step >= half) {
+      // PREPARE: epilogue of the tile computed in the previous step, then the patch of the next one
+      const int qn = done_q >= 0 ? mail[half] : -1;   // (published by the barrier that closed the COMPUTE step)
+      if (done_q >= 0) {
+        wino_epilogue<HAS_R>(acc, fin, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1);
+        done_q = -1;
+      }
+      q = qn;
+      if (q >= 0) {
+        cur = wino_decode(q, tiles_w, tiles_hw, 1, 8, 32, num_pb);
+        wino_issue_patch<4, 1>(X, H, W, CIN, cur, 0, patch, prel, slw, x0_last);
+        wino_issue_patch<4, 1>(X, H, W, CIN, cur, WCB, patch + G::PATCH, prel, slw, x0_last);
+        if (leader) ahead = tq_claim_own(tq);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    wino_barrier();
+    if (mail[2] == 0 && mail[3] == 0) break;
+  }
+  if (tid == 0) tq_done(tq, gridDim.x);
+}
+
+template <bool HAS_R>
+static int launch_wino32(const float* X, int B, int H, int W, const float* U, const float* shift, const float* R,
+                         float* Y, int relu, hipStream_t st) {
+  using G = WinoGeom<4, 1>;
+  const int tiles_w = cdiv(W, 32), tiles_h = cdiv(H, 8);
+  const size_t lds = (size_t)(2 * G::USLAB + 4 * G::PATCH) * sizeof(float) + 32;
+  auto kernel = k_conv3x3_wino32<HAS_R>;
+  constexpr int MAXDEV = 16;
+  static int cus_of[MAXDEV] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= MAXDEV) dev = 0;
+  if (!cus_of[dev]) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus_of[dev] = cus;
+  }
+  const int tiles_hw = tiles_w * tiles_h;
+  const long num_pb = (long)tiles_hw * B;
+  const long total = ((num_pb + 7) / 8) * 8;
+  const int resident = cus_of[dev] & ~7;            // one workgroup (two halves) per CU
+  const long want = (total + 1) / 2;
+  const int grid = (int)(want < resident ? ((want + 7) & ~7L) : resident);
+  int* counters = tile_counters();
+  if (counters == nullptr) {
+    set_error("pa_conv3x3_wino: cannot allocate the tile counters");
+    return 2;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, st, X, H, W, U, shift, R, Y, relu, tiles_w, tiles_hw,
+                     (int)total, (int)num_pb, counters);
+  return 0;
+}
+
 template <int TR, int TCG>
 static int launch_wino(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                        const float* R, float* Y, int COUT, int relu, hipStream_t st) {
@@ -518,7 +661,12 @@ int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U
     return (long)pa::cdiv(H, 2 * tr) * 2 * tr * (long)pa::cdiv(W, 32 * tcg) * 32 * tcg;
   };
   const long a41 = padded(4, 1), a22 = padded(2, 2), a14 = padded(1, 4);
-  if (a41 <= a22 && a41 <= a14) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  static const bool wino32 = getenv("PA_WINO32") == nullptr || atoi(getenv("PA_WINO32")) != 0;   // A/B aid
+  if (wino32 && cin == 32 && cout == 32 && a41 <= a22 && a41 <= a14) {
+    const int rc = R != nullptr ? pa::launch_wino32<true>(X, B, H, W, U, shift, R, Y, relu, st)
+                                : pa::launch_wino32<false>(X, B, H, W, U, shift, R, Y, relu, st);
+    if (rc != 0) return rc;
+  } else if (a41 <= a22 && a41 <= a14) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   else if (a22 <= a14) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   else pa::launch_wino<1, 4>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   PA_CHECK_LAUNCH("pa_conv3x3_wino");
