@@ -33,7 +33,7 @@ def sweep(name, X, scipy_check):
         t = time.perf_counter()
         ref = linkage(pdist(X), "centroid")
         print(f"{name}: scipy pdist + linkage {1e3 * (time.perf_counter() - t):.0f} ms", flush=True)
-    for G in (1, 2, 4, 8, 16):
+    for G in [int(g) for g in os.environ.get("LK_GS", "1,2,4,8,16").split(",")]:
         Z, dt, info = run(X, G)
         if ref is None:
             ref = Z
