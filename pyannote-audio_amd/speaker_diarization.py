@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import math
 import textwrap
+import threading
 import time
 import warnings
 from concurrent.futures import ThreadPoolExecutor
@@ -77,6 +78,10 @@ class _FrontEnd:
 
 
 class SpeakerDiarization(Pipeline):
+    # pipelined batches: longest wait (s) of a file's tail for the next file's segmentation stage (a safety net:
+    # the gate is opened in a `finally`)
+    TAIL_GATE_TIMEOUT = 5.0
+
     def __init__(self, legacy: bool = False, segmentation: PipelineModel = None,
                  segmentation_step: float = 0.1, embedding: PipelineModel = None,
                  embedding_exclude_overlap: bool = False, plda: Any = None,
@@ -241,7 +246,9 @@ class SpeakerDiarization(Pipeline):
                                        hard_clusters, count.data).discretize()
 
     # ---------------------------------------------------------------------------------- front end
-    def _front_end(self, file: dict, hook: Callable) -> _FrontEnd:
+    def _front_end(self, file: dict, hook: Callable, after_segmentation: Optional[Callable] = None) -> _FrontEnd:
+        """`after_segmentation()` is called once the segmentation stage has LEFT the device (the pipelined
+        batch forms release the previous file's tail there)."""
         marks = [("start", time.perf_counter())]
         waveform = self._load(file)
         marks.append(("load", time.perf_counter()))
@@ -265,6 +272,8 @@ class SpeakerDiarization(Pipeline):
             dev_scores = dev_seg
             dev_seg = frame_ops.binarize(dev_scores, onset=self.segmentation.threshold, initial_state=False)
         marks.append(("segmentation", time.perf_counter()))
+        if after_segmentation is not None:
+            after_segmentation()
         enqueued = {"segmentation": self._segmentation.last_enqueued}
 
         dev_emb = active = clean = None
@@ -467,30 +476,46 @@ class SpeakerDiarization(Pipeline):
         # (csrc/common.h: TileQueue), so the workgroups that cannot be placed beside the merge merely find
         # nothing left to do; with the earlier static tile partition they started a whole round late and every
         # convolution launch under the merge took 1.6x as long (tools/probes/interference_probe.py).
+        # The SEGMENTATION kernels are ordinary one-round grids (k_lstm_rec: 450 workgroups that live for the whole
+        # launch): the one that shares its CU with the merge is slowed and the launch ends with it (+26 %, stage
+        # +20 ms per audio-hour, tools/batch_prof.py).  So the tail of file i is GATED: it starts when the
+        # segmentation stage of file i+1 has left the device (or there is no next file) and overlaps only the
+        # embedding stage.
         t_batch = time.perf_counter()
         self.batch_timeline = []               # per file: host-clock offsets (s) of the stage boundaries
 
-        def tail_timed(front: _FrontEnd, file_hook: Callable, line: dict, bounds: tuple):
+        def tail_timed(front: _FrontEnd, file_hook: Callable, line: dict, bounds: tuple, gate: threading.Event):
             line["tail_start"] = time.perf_counter() - t_batch
+            if not front.silent:
+                gate.wait(timeout=self.TAIL_GATE_TIMEOUT)
+            line["tail_released"] = time.perf_counter() - t_batch
             out = tail(front, file_hook, bounds)
             line["tail_done"] = time.perf_counter() - t_batch
             return out
 
         with ThreadPoolExecutor(max_workers=1) as pool:
-            in_flight = None
-            for file, bounds in zip(files, all_bounds):
-                file_hook = self.setup_hook(file, hook=hook)
-                line = {"front_start": time.perf_counter() - t_batch}
-                front = self._front_end(file, file_hook)
-                line.update({name: stamp - t_batch for name, stamp in front.marks[1:]})
-                line.update({name + "_queued": stamp - t_batch for name, stamp in front.enqueued.items()})
-                self.batch_timeline.append(line)
+            in_flight = gate = None
+            try:
+                for file, bounds in zip(files, all_bounds):
+                    file_hook = self.setup_hook(file, hook=hook)
+                    line = {"front_start": time.perf_counter() - t_batch}
+                    front = self._front_end(file, file_hook, after_segmentation=gate.set if gate else None)
+                    if gate is not None:
+                        gate.set()
+                    line.update({name: stamp - t_batch for name, stamp in front.marks[1:]})
+                    line.update({name + "_queued": stamp - t_batch for name, stamp in front.enqueued.items()})
+                    self.batch_timeline.append(line)
+                    if in_flight is not None:
+                        yield in_flight[0], in_flight[1].result()
+                    line["submit"] = time.perf_counter() - t_batch
+                    gate = threading.Event()
+                    in_flight = (file, pool.submit(tail_timed, front, file_hook, line, bounds, gate))
                 if in_flight is not None:
+                    gate.set()                                  # no next file
                     yield in_flight[0], in_flight[1].result()
-                line["submit"] = time.perf_counter() - t_batch
-                in_flight = (file, pool.submit(tail_timed, front, file_hook, line, bounds))
-            if in_flight is not None:
-                yield in_flight[0], in_flight[1].result()
+            finally:
+                if gate is not None:
+                    gate.set()                                  # (a failing front end must not strand the tail)
 
     def _apply_jointly(self, files: List[dict], bounds, hook, device: torch.device):
         """front end per file; records of all files of all ranks gathered on the device; ONE clustering
@@ -511,27 +536,40 @@ class SpeakerDiarization(Pipeline):
         device = self._require_device()
         side = torch.cuda.Stream(device=device)
 
-        def finish(job):
+        def finish(job, gate: threading.Event):
+            gate.wait(timeout=self.TAIL_GATE_TIMEOUT)   # (as in apply_batch: not beside a segmentation stage)
             with torch.cuda.device(device), torch.cuda.stream(side):
                 out = list(self._joint_finish(job, bounds))
                 side.synchronize()
             return out
 
         with ThreadPoolExecutor(max_workers=1) as pool:
-            in_flight = None
-            for group in groups:
-                job = self._joint_gather([Audio.validate_file(f) for f in group], hook, device)
+            in_flight = gate = None
+            try:
+                for group in groups:
+                    job = self._joint_gather([Audio.validate_file(f) for f in group], hook, device,
+                                             after_segmentation=gate.set if gate else None)
+                    if gate is not None:
+                        gate.set()
+                    if in_flight is not None:
+                        yield in_flight.result()
+                    gate = threading.Event()
+                    in_flight = pool.submit(finish, job, gate)
                 if in_flight is not None:
+                    gate.set()
                     yield in_flight.result()
-                in_flight = pool.submit(finish, job)
-            if in_flight is not None:
-                yield in_flight.result()
+            finally:
+                if gate is not None:
+                    gate.set()
 
-    def _joint_gather(self, files: List[dict], hook, device: torch.device) -> dict:
+    def _joint_gather(self, files: List[dict], hook, device: torch.device,
+                      after_segmentation: Optional[Callable] = None) -> dict:
         """first half of a joint job: front ends of the local files + the exchange of the per-chunk records of
         all ranks (the only collectives of the path)"""
         hooks = [self.setup_hook(f, hook=hook) for f in files]
-        fronts = [self._front_end(f, h) for f, h in zip(files, hooks)]
+        # (`after_segmentation`: after the LAST local file's segmentation stage -- a joint tail is long anyway)
+        fronts = [self._front_end(f, h, after_segmentation if i == len(files) - 1 else None)
+                  for i, (f, h) in enumerate(zip(files, hooks))]
         voiced = [fr for fr in fronts if not fr.silent]
         shard = parallel.shard_from_env() if parallel.current_shard().world_size == 1 else parallel.Shard()
         job = {"fronts": fronts, "hooks": hooks, "voiced": voiced, "empty": False}
