@@ -627,14 +627,18 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
     const double dist = lk_ld<true>(&sh->dist);
     // ---- this workgroup's slices of the pass over all clusters z
     MinPair best{__builtin_inf(), -1};
-    for (int z0 = wg * 4 * LK_T + tid; z0 < n; z0 += G * 4 * LK_T) {
+    // (contiguous slices of ~n / G clusters: at n = 7 k and 8 workgroups every thread owns ONE cluster -- the pass
+    //  is bound by the f64 division / square root throughput of a CU, so it has to be spread evenly)
+    const int slice = (((n + G - 1) / G) + 63) & ~63;
+    const int z_end = min(n, (wg + 1) * slice);
+    for (int z0 = wg * slice + tid; z0 < z_end; z0 += 4 * LK_T) {
       bool act[4];
       long izy[4];
       double d_xi[4], d_yi[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int z = z0 + u * LK_T;
-        act[u] = z < n && z != y && lk_ld<true>(size + z) != 0;
+        act[u] = z < z_end && z != y && lk_ld<true>(size + z) != 0;
         izy[u] = act[u] ? cidx(n, z, y) : 0;
         d_xi[u] = act[u] ? lk_ld<true>(D + cidx(n, z, x)) : 0.0;
         d_yi[u] = act[u] ? lk_ld<true>(D + izy[u]) : 0.0;
@@ -773,6 +777,8 @@ static int lk_num_workgroups(int n) {
   // embeddings (profiles/r3_joint_scale.txt) 16 workgroups take 0.92 -> 0.78 s at N = 14 k (8 workgroups: 0.72 s),
   // 3.59 -> 2.02 s at 29 k, 14.2 -> 6.7 s at 57 k; on the 4-blob synthetic set of tools/time_linkage.py, which needs
   // 10x as many heap updates per merge, only the largest size gains (profiles/r3_linkage_multi_workgroup.txt).
+  // One audio-hour (N = 7 176, profiles/r3_linkage_even_split.txt): 8 workgroups 183 ms vs 195 ms alone, but beside
+  // the next file's embedding stage they cost that stage 5 ms -- one workgroup stays the default below 12 k.
   // <= 16 workgroups: two concurrent merges (two processes on one GPU) still fit one XCD.
   return n >= 20000 ? 16 : (n >= 12000 ? 8 : 1);
 }
