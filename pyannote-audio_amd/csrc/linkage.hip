@@ -164,6 +164,7 @@ __device__ MinPair block_find_min(const double* __restrict__ D, const int* __res
   return r;
 }
 
+constexpr int LK_PU = 8;    // clusters per thread and trip of the single-workgroup z pass
 constexpr int LK_PEND = 256;  // lower-bound drops buffered per merge (more -> re-read from D)
 
 template <typename IT, bool LDS_HEAP>
@@ -318,13 +319,14 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
     // which is replayed afterwards): Lance-Williams (centroid) update of D[z,y]; neighbour
     // reassignment x -> y for z < x; lower-bound refresh for z < y; nearest neighbour of y among z > y.
     MinPair best{__builtin_inf(), -1};
-    for (int z0 = tid; z0 < n; z0 += 4 * LK_T) {
-      // 4 clusters per thread: all 8 distance loads are issued before the first use
-      bool act[4];
-      long izy[4];
-      double d_xi[4], d_yi[4];
+    for (int z0 = tid; z0 < n; z0 += LK_PU * LK_T) {
+      // LK_PU clusters per thread: all distance loads are issued before the first use (one audio-hour = 7 176
+      // clusters = ONE trip: the pass is a latency chain, a second trip doubles it)
+      bool act[LK_PU];
+      long izy[LK_PU];
+      double d_xi[LK_PU], d_yi[LK_PU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LK_PU; ++u) {
         const int z = z0 + u * LK_T;
         act[u] = z < n && z != y && size[z] != 0;
         izy[u] = act[u] ? cidx(n, z, y) : 0;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
         d_yi[u] = act[u] ? D[izy[u]] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LK_PU; ++u) {
         if (!act[u]) continue;
         const int z = z0 + u * LK_T;
         const double nd = sqrt(
