@@ -75,15 +75,22 @@ __global__ __launch_bounds__(320) void k_sinc_fir_pool(
   // stage normalised samples [PS*p0, PS*p0 + nstage)
   const long cbase = (long)b * chunk_stride;
   const float mu = mean[b], rs = rstd[b] * gamma;
-  for (int i = tid; i < SINC_XS; i += 320) {
-    const int sidx = PS * p0 + i;
-    float v = 0.f;
-    if (sidx < N) {
-      const long g = cbase + sidx;
-      const float raw = g < wav_len ? wav[g] : 0.f;
-      v = (raw - mu) * rs + beta;
+  // (all loads of a thread are issued before the first use: as a plain loop the compiler waits for every load
+  //  in turn -- 13 exposed memory latencies per workgroup)
+  {
+    constexpr int NS = (SINC_XS + 319) / 320;
+    float raw[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int i = tid + 320 * k;
+      const long g = cbase + PS * p0 + i;
+      raw[k] = (i < SINC_XS && PS * p0 + i < N && g < wav_len) ? wav[g] : 0.f;
     }
-    xs[i] = v;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int i = tid + 320 * k;
+      if (i < SINC_XS) xs[i] = PS * p0 + i < N ? (raw[k] - mu) * rs + beta : 0.f;
+    }
   }
   // filter taps -> registers (B operand)
   float fb[63];
@@ -146,16 +153,35 @@ __global__ __launch_bounds__(256) void k_conv5_pool(const float* __restrict__ xi
   const int p0 = blockIdx.x * CV_PT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
-  for (int i = tid; i < CIN * CV_XW; i += 256) {
-    const int c = i / CV_XW, q = i % CV_XW;
-    const int pos = 3 * p0 + q;
-    float v = 0.f;
-    if (q < 3 * CV_PT + 4 && pos < Lin) {
-      const int row = b * CIN + c;
-      v = (xin[(long)row * Lin + pos] - in_mean[row]) * (in_rstd[row] * gam[c]) + bet[c];
-      v = leaky_relu(v);
+  // stage: wave w owns channel rows w, w + 4, ...; a lane covers positions lane and lane + 64 of the row.  Five
+  // rows (10 loads + their statistics) are in flight per trip: the element-wise loop this replaces waited for
+  // each of its 35 loads in turn (+ a division and four statistic loads per element).
+  {
+    static_assert(CIN % 20 == 0, "five channel rows per wave and trip");
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int q1 = lane + 64;
+    const bool ok0 = 3 * p0 + lane < Lin;                        // (lane < 3 * CV_PT + 4 always)
+    const bool ok1 = q1 < 3 * CV_PT + 4 && 3 * p0 + q1 < Lin;
+#pragma unroll
+    for (int j0 = 0; j0 < CIN / 4; j0 += 5) {
+      float x0[5], x1[5], mu[5], sc[5], sh[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int c = wu + 4 * (j0 + u), row = b * CIN + c;
+        const float* src = xin + (long)row * Lin + 3 * p0;
+        x0[u] = ok0 ? src[lane] : 0.f;
+        x1[u] = ok1 ? src[q1] : 0.f;
+        mu[u] = in_mean[row];
+        sc[u] = in_rstd[row] * gam[c];
+        sh[u] = bet[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        float* dst = xs + (wu + 4 * (j0 + u)) * CV_XW;
+        dst[lane] = ok0 ? leaky_relu((x0[u] - mu[u]) * sc[u] + sh[u]) : 0.f;
+        if (q1 < CV_XW) dst[q1] = ok1 ? leaky_relu((x1[u] - mu[u]) * sc[u] + sh[u]) : 0.f;
+      }
     }
-    xs[i] = v;
   }
   float wb[KT];
 #pragma unroll
