@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
 
 // ---------------------------------------------------------------------------------------------
 // Sinc FIR + abs + maxpool3.
-//   grid = (ceil(P / PT), B), block = 320 (5 waves; wave w owns filters 16w..16w+15).
+//   grid = (ceil(P / PT), B), block = 640: wave w owns filters 16 (w % 5) .. + 15 and HALF of the workgroup's
+//   positions (w / 5).  Ten waves, not five: 80 filters are five 16-wide MFMA tiles, and five waves put two on
+//   SIMD 0 and one on each other SIMD (the launch then runs at the pace of SIMD 0, 5/8 of the CU); ten waves sit
+//   3-3-2-2.
 //   filt : B-operand image [5][63][64] : filt[(w*63+kt)*64 + lane] = h[16w + (lane&15)][4kt + (lane>>4)]
 //          (tap 251 is zero padding).
 //   out  : (B, 80, P) un-normalised pooled magnitudes.
@@ -58,8 +61,9 @@ __global__ __launch_bounds__(256) void k_row_stats(const float* __restrict__ x, 
 constexpr int SINC_PT = 128;                       // pooled outputs per workgroup
 constexpr int SINC_XS = 30 * SINC_PT + 256;        // staged samples (>= 30*PT + 242)
 constexpr int SINC_OS = SINC_PT + 4;               // out-tile row stride in LDS
+constexpr int SINC_T = 640;                        // threads
 
-__global__ __launch_bounds__(320) void k_sinc_fir_pool(
+__global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
     const float* __restrict__ wav, long wav_len, long chunk_stride, int N, int stride, int P,
     const float* __restrict__ mean, const float* __restrict__ rstd, float gamma, float beta,
     const float* __restrict__ filt, float* __restrict__ out) {
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(320) void k_sinc_fir_pool(
   float* os = smem + SINC_XS;      // [80][SINC_OS]
   const int b = blockIdx.y;
   const int p0 = blockIdx.x * SINC_PT;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = (tid >> 6) % 5, half = (tid >> 6) / 5;   // filter tile, half of the positions
   constexpr int STR = 10;          // SincNet stride (checked by the host wrapper)
   constexpr int PS = 3 * STR;      // sample advance per pooled output
 
@@ -76,19 +81,19 @@ __global__ __launch_bounds__(320) void k_sinc_fir_pool(
   const long cbase = (long)b * chunk_stride;
   const float mu = mean[b], rs = rstd[b] * gamma;
   // (all loads of a thread are issued before the first use: as a plain loop the compiler waits for every load
-  //  in turn -- 13 exposed memory latencies per workgroup)
+  //  in turn)
   {
-    constexpr int NS = (SINC_XS + 319) / 320;
+    constexpr int NS = (SINC_XS + SINC_T - 1) / SINC_T;
     float raw[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      const int i = tid + 320 * k;
+      const int i = tid + SINC_T * k;
       const long g = cbase + PS * p0 + i;
       raw[k] = (i < SINC_XS && PS * p0 + i < N && g < wav_len) ? wav[g] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      const int i = tid + 320 * k;
+      const int i = tid + SINC_T * k;
       if (i < SINC_XS) xs[i] = PS * p0 + i < N ? (raw[k] - mu) * rs + beta : 0.f;
     }
   }
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(320) void k_sinc_fir_pool(
 
   const int i16 = lane & 15, kq = lane >> 4;
 #pragma unroll 1
-  for (int grp = 0; grp < SINC_PT / 16; ++grp) {
+  for (int grp = half * (SINC_PT / 32); grp < (half + 1) * (SINC_PT / 32); ++grp) {
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
     const float* xp = xs + PS * (16 * grp + i16) + kq;
 #pragma unroll
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(320) void k_sinc_fir_pool(
   }
   __syncthreads();
   const int np = min(SINC_PT, P - p0);
-  for (int i = tid; i < 80 * SINC_PT; i += 320) {
+  for (int i = tid; i < 80 * SINC_PT; i += SINC_T) {
     const int c = i / SINC_PT, p = i % SINC_PT;
     if (p < np) out[((long)b * 80 + c) * P + p0 + p] = os[c * SINC_OS + p];
   }
@@ -278,7 +283,7 @@ int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, i
                             (int)lds);
   pa::ProfScope prof("k_sinc_fir_pool", stream, 2.0 * B * 80 * 251 * (3.0 * P),
                      4.0 * B * N + 4.0 * B * 80 * P);
-  hipLaunchKernelGGL(pa::k_sinc_fir_pool, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(320), lds,
+  hipLaunchKernelGGL(pa::k_sinc_fir_pool, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(pa::SINC_T), lds,
                      (hipStream_t)stream, wav, wav_len, chunk_stride, N, stride, P, mean, rstd, gamma,
                      beta, filt_packed, out);
   PA_CHECK_LAUNCH("pa_sinc_fir_pool");
