@@ -61,6 +61,9 @@
 #endif
 // (nt / "streaming" cache-policy bits on the patch DMA, the residual loads or the stores: measured neutral to
 //  10-25 % slower, profiles/r3_wino_cache_policy.txt -- every access keeps the default policy)
+#ifndef PA_WINO_RTOUCH
+#define PA_WINO_RTOUCH 1
+#endif
 #ifndef PA_WINO_RPRE   // residual prefetch through LDS in front of a tile's last MFMA run (-DPA_WINO_RPRE=0: A/B)
 #define PA_WINO_RPRE 1
 #endif
@@ -358,6 +361,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   // on the 4 x 64-pixel tiles (128 channels) it LOSES 1 % and the 2 x 128-pixel tiles have no LDS left for it.
   constexpr bool RPRE = PA_WINO_RPRE && HAS_R && TCG == 1;
   float* rbuf = smem + G::LDS_FLOATS + 4 + 1024 * slw;
+  // the 2 x 128-pixel tiles (256 channels) only TOUCH their residual lines ahead of the tile's last MFMA run (one
+  // 4-byte DMA piece per wave into a 256-B scratch row that nobody reads): the epilogue's loads then hit L2.
+  // Measured (B = 512, profiles/r3_wino_residual_touch.txt): 10x125x256 3.157 -> 3.099 ms; the 4 x 64-pixel tiles
+  // (128 channels) LOSE 2 % with it (3.18 -> 3.24 ms), like they lose with the LDS staging above.
+  constexpr bool RTOUCH = PA_WINO_RTOUCH && HAS_R && TCG == 4;
   // tiles are CLAIMED, not statically strided (common.h: TileQueue): thread 0 claims the next tile while
   // the current one is processed and publishes it through LDS at the tile boundary
   int* s_next = reinterpret_cast<int*>(smem + G::LDS_FLOATS);
@@ -409,6 +417,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
           for (int e = 0; e < 4; ++e)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrd, (lds_ptr_t)(rbuf + 256 * e), 16, off_pre[e], 0, 0, 0);
         }
+        if (RTOUCH && c0 + WCB >= CIN) {
+          // one pixel (= one 128-B line of this workgroup's 32 output channels) per thread; its own few
+          // integer operations, so that nothing of the epilogue's offsets is kept alive across the MFMA run
+          // (wave slw covers 64 consecutive pixels of tile row 64 slw / (32 TCG): scalar base + lane * COUT * 4)
+          const int yy = cur.y0 + (64 * slw) / (32 * TCG), xb = cur.x0 + (64 * slw) % (32 * TCG);
+          const int sbase = ((yy * W + xb) * COUT + cur.n0) * 4;
+          const int off = (yy < H && xb + lane < W) ? sbase + lane * COUT * 4 : H * W * COUT * 4;
+          const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<float*>(R + (long)cur.b * H * W * COUT), 0, H * W * COUT * 4, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrd, (lds_ptr_t)(smem + G::LDS_FLOATS + 4 + 64 * slw), 4, off, 0,
+                                                   0, 0);
+        }
         if (c0 == 0) wino_mfma<true>(uslab, v, acc, t, g);
         else wino_mfma<false>(uslab, v, acc, t, g);
         WINO_STAMP(6);
@@ -439,7 +459,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
   const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
   // + the claimed-tile mailbox (+ 16 KB of residual staging where it is used: k_conv3x3_wino RPRE)
   const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + 16 +
-                     ((PA_WINO_RPRE && HAS_R && TCG == 1) ? 4 * 4096 : 0);
+                     ((PA_WINO_RPRE && HAS_R && TCG == 1) ? 4 * 4096 : (PA_WINO_RTOUCH && HAS_R && TCG == 4 ? 4 * 256 : 0));
   auto kernel = k_conv3x3_wino<TR, TCG, HAS_R>;
   // per-device launch state (the attribute and the CU count belong to a device, not to the process)
   constexpr int MAXDEV = 16;
