@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wav, lo
   const int t = blockIdx.x * FB_FPB + wv;
   for (int i = tid; i < FB_HALF; i += 256) s_tw256[i] = tw256[i];
   const bool active = t < T;
+  float2 w512[5];     // twiddles of the real unpack: fetched now, used after the FFT
+#pragma unroll
+  for (int i = 0; i < 5; ++i) w512[i] = lane + 64 * i <= FB_HALF ? tw512[lane + 64 * i] : make_float2(0.f, 0.f);
 
   // ---- load + scale, DC removal
   float x[7];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wav, lo
       const cplx e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y)};
       const cplx dd = {0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y)};
       const cplx o = {dd.y, -dd.x};  // -i * dd
-      const float2 w = tw512[k];
+      const float2 w = w512[i];
       const cplx wo = cmul(o, {w.x, w.y});
       const float re = e.x + wo.x, im = e.y + wo.y;
       xw[k] = re * re + im * im;
@@ -143,7 +146,17 @@ __global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wav, lo
     for (int m = lane; m < nmel; m += 64) {
       const float* wrow = mel_w + (long)m * FB_NBIN;
       float acc = 0.f;
-      for (int k = mel_lo[m]; k <= mel_hi[m]; ++k) acc = fmaf(xw[k], wrow[k], acc);
+      // eight weights in flight per trip (a plain loop waits for every weight in turn: ~30 L2 round trips per
+      // mel bin, which was most of this kernel's time); the fma chain keeps its order in k
+      const int lo = mel_lo[m], hi = mel_hi[m];
+      for (int k0 = lo; k0 <= hi; k0 += 8) {
+        float wk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wk[u] = k0 + u <= hi ? wrow[k0 + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u <= hi) acc = fmaf(xw[k0 + u], wk[u], acc);
+      }
       out[((long)b * T + t) * nmel + m] = logf(fmaxf(acc, eps));
     }
   }

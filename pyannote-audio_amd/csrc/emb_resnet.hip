@@ -16,48 +16,95 @@ namespace pa {
 
 // ---------------------------------------------------------------------------------------------
 // stem: out[b][f][t][c] = relu( sum_{df,dt} w[c][df][dt] * fb[b][t+dt-1][f+df-1] + shift[c] )
-// grid = (ceil(T/64), F, B), block = 256: thread = (pixel t, 8-channel group)
+// grid = (ceil(T/64), B), block = 256: thread = (time step p of 64, 8-channel group); a workgroup walks ALL mel
+// rows of its 64 time steps.  The 72 weights + 8 shifts of a thread stay in registers, the (66 x F) slice of the
+// fbank is staged once (coalesced along F, transposed in LDS), every step writes 2 KB contiguous per wave.  (One
+// workgroup per 64 pixels of ONE mel row, as before, was 4.6 M workgroups per audio-hour, each reloading the
+// weights and reading the fbank with a stride of F floats: 12 ms at 3.2 TB/s for a kernel that only has to write.)
 // ---------------------------------------------------------------------------------------------
+constexpr int STEM_TS = 64;             // time steps per workgroup
+constexpr int STEM_LD = STEM_TS + 3;    // LDS row stride (odd: the transposing stores spread over the banks)
+
 __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ fb, int T, int F,
                                               const float* __restrict__ w9,   // [9][32] tap-major
                                               const float* __restrict__ shift,  // [32]
                                               float* __restrict__ out) {
-  __shared__ float xs[3][66];
-  __shared__ float ws[9 * 32 + 32];
-  const int b = blockIdx.z, f = blockIdx.y, t0 = blockIdx.x * 64;
+  extern __shared__ float xs[];         // [(F + 2)][STEM_LD]: row f + 1 = mel bin f, column tt = time t0 - 1 + tt
+  const int b = blockIdx.y, t0 = blockIdx.x * STEM_TS;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 9 * 32 + 32; i += 256) ws[i] = i < 288 ? w9[i] : shift[i - 288];
-  for (int i = tid; i < 3 * 66; i += 256) {
-    const int df = i / 66, tt = i % 66;
-    const int ff = f + df - 1, t = t0 + tt - 1;
-    xs[df][tt] = (ff >= 0 && ff < F && t >= 0 && t < T) ? fb[((long)b * T + t) * F + ff] : 0.f;
+  // zero the two halo rows, then stage: consecutive threads read consecutive mel bins of one frame
+  for (int i = tid; i < 2 * STEM_LD; i += 256) xs[(i < STEM_LD ? 0 : (F + 1) * STEM_LD - STEM_LD) + i] = 0.f;
+  const int n = (STEM_TS + 2) * F;
+  for (int i0 = 0; i0 < n; i0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {       // 8 loads in flight per thread
+      const int i = i0 + tid + 256 * k;
+      const int tt = i / F, ff = i - tt * F, t = t0 + tt - 1;
+      v[k] = (i < n && t >= 0 && t < T) ? fb[((long)b * T + t) * F + ff] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + tid + 256 * k;
+      const int tt = i / F, ff = i - tt * F;
+      if (i < n) xs[(ff + 1) * STEM_LD + tt] = v[k];
+    }
   }
+  const int p = tid >> 2, cg = (tid & 3) * 8;
+  float w[9][8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[k][c] = w9[k * 32 + cg + c];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sh[c] = shift[cg + c];
   __syncthreads();
-  const int px = tid >> 2, cg = (tid & 3) * 8;
-  if (t0 + px >= T) return;
-  float acc[8];
+  if (t0 + p >= T) return;
+  // rolling 3 x 3 window: rows f - 1, f, f + 1 (LDS rows f, f + 1, f + 2), columns p .. p + 2
+  float x0[3], x1[3], x2[3];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int dt = 0; dt < 3; ++dt) {
+    x0[dt] = xs[0 * STEM_LD + p + dt];
+    x1[dt] = xs[1 * STEM_LD + p + dt];
+  }
+  float* o = out + ((long)b * F * T + t0 + p) * 32 + cg;
+  for (int f = 0; f < F; ++f) {
 #pragma unroll
-  for (int df = 0; df < 3; ++df)
+    for (int dt = 0; dt < 3; ++dt) x2[dt] = xs[(f + 2) * STEM_LD + p + dt];
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    // (df outer, dt inner: the summation order of the previous kernel, so the results are bit-identical)
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(x0[dt], w[dt][c], acc[c]);
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(x1[dt], w[3 + dt][c], acc[c]);
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(x2[dt], w[6 + dt][c], acc[c]);
+    float4 o0, o1;
+    o0.x = fmaxf(acc[0] + sh[0], 0.f);
+    o0.y = fmaxf(acc[1] + sh[1], 0.f);
+    o0.z = fmaxf(acc[2] + sh[2], 0.f);
+    o0.w = fmaxf(acc[3] + sh[3], 0.f);
+    o1.x = fmaxf(acc[4] + sh[4], 0.f);
+    o1.y = fmaxf(acc[5] + sh[5], 0.f);
+    o1.z = fmaxf(acc[6] + sh[6], 0.f);
+    o1.w = fmaxf(acc[7] + sh[7], 0.f);
+    float* of = o + (long)f * T * 32;
+    reinterpret_cast<float4*>(of)[0] = o0;
+    reinterpret_cast<float4*>(of)[1] = o1;
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt) {
-      const float xv = xs[df][px + dt];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv, ws[(df * 3 + dt) * 32 + cg + c], acc[c]);
+      x0[dt] = x1[dt];
+      x1[dt] = x2[dt];
     }
-  float* o = out + (((long)b * F + f) * T + t0 + px) * 32 + cg;
-  float4 o0, o1;
-  o0.x = fmaxf(acc[0] + ws[288 + cg + 0], 0.f);
-  o0.y = fmaxf(acc[1] + ws[288 + cg + 1], 0.f);
-  o0.z = fmaxf(acc[2] + ws[288 + cg + 2], 0.f);
-  o0.w = fmaxf(acc[3] + ws[288 + cg + 3], 0.f);
-  o1.x = fmaxf(acc[4] + ws[288 + cg + 4], 0.f);
-  o1.y = fmaxf(acc[5] + ws[288 + cg + 5], 0.f);
-  o1.z = fmaxf(acc[6] + ws[288 + cg + 6], 0.f);
-  o1.w = fmaxf(acc[7] + ws[288 + cg + 7], 0.f);
-  reinterpret_cast<float4*>(o)[0] = o0;
-  reinterpret_cast<float4*>(o)[1] = o1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,8 +436,9 @@ int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, con
                    float* out, void* stream) {
   if (B <= 0) return 0;
   pa::ProfScope prof("k_stem", stream, 2.0 * B * T * F * 9 * 32, 4.0 * B * T * F * 33);
-  hipLaunchKernelGGL(pa::k_stem, dim3(pa::cdiv(T, 64), F, B), dim3(256), 0, (hipStream_t)stream, fbank,
-                     T, F, w9, shift, out);
+  PA_REQUIRE(F >= 1 && (size_t)(F + 2) * pa::STEM_LD * 4 <= 64 * 1024, "pa_resnet_stem: %d mel bins do not fit LDS", F);
+  hipLaunchKernelGGL(pa::k_stem, dim3(pa::cdiv(T, pa::STEM_TS), B), dim3(256), (size_t)(F + 2) * pa::STEM_LD * 4,
+                     (hipStream_t)stream, fbank, T, F, w9, shift, out);
   PA_CHECK_LAUNCH("pa_resnet_stem");
   return 0;
 }
