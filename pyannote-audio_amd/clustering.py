@@ -141,20 +141,25 @@ class BaseClustering(Pipeline):
             hard[c, speakers] = clusters
         return hard
 
-    def _similarities(self, embeddings: np.ndarray, centroids: np.ndarray) -> np.ndarray:
-        """soft (C, S, K) = 2 - distance of every (chunk, speaker) embedding to every centroid"""
+    def _similarities(self, embeddings: np.ndarray, centroids: np.ndarray, device_embeddings=None) -> np.ndarray:
+        """soft (C, S, K) = 2 - distance of every (chunk, speaker) embedding to every centroid.
+        `device_embeddings`: the same (C, S, D) values as a device tensor, when the caller still has them there
+        (saves the float64 conversion on the host and the upload)."""
         C, S, D = embeddings.shape
-        d = distance.cdist(embeddings.reshape(C * S, D), centroids, metric=self.metric, device=self.device)
+        A = embeddings.reshape(C * S, D)
+        if device_embeddings is not None and tuple(device_embeddings.shape) == (C, S, D):
+            A = device_embeddings.reshape(C * S, D)
+        d = distance.cdist(A, centroids, metric=self.metric, device=self.device)
         return 2 - d.reshape(C, S, -1)
 
     def assign_embeddings(self, embeddings: np.ndarray, train_chunk_idx: np.ndarray,
                           train_speaker_idx: np.ndarray, train_clusters: np.ndarray,
-                          constrained: bool = False):
+                          constrained: bool = False, device_embeddings=None):
         """centroid of every cluster from the (un-normalised) training embeddings, then every
         (chunk, speaker) goes to its most similar centroid (clustering.py:142-212)"""
         centroids = segment_means(embeddings[train_chunk_idx, train_speaker_idx], train_clusters,
                                   int(np.max(train_clusters)) + 1)
-        soft = self._similarities(embeddings, centroids)
+        soft = self._similarities(embeddings, centroids, device_embeddings)
         hard = self.constrained_argmax(soft) if constrained else np.argmax(soft, axis=2)
         return hard, soft, centroids
 
@@ -181,7 +186,8 @@ class BaseClustering(Pipeline):
                               num_clusters=num_clusters)
         t1 = time.perf_counter()
         out = self.assign_embeddings(embeddings, chunk_idx, speaker_idx, labels,
-                                     constrained=self.constrained_assignment)
+                                     constrained=self.constrained_assignment,
+                                     device_embeddings=kwargs.get("device_embeddings"))
         self.timings.update(cluster=t1 - t0, assign=time.perf_counter() - t1)
         return out
 

@@ -68,11 +68,16 @@ last_linkage_stats = None
 
 
 @ffi.on_device(lambda A, B, metric="cosine", device=None: device)
-def cdist(A: np.ndarray, B: np.ndarray, metric: str = "cosine", device=None) -> np.ndarray:
+def cdist(A, B: np.ndarray, metric: str = "cosine", device=None) -> np.ndarray:
+    """`A`: host array, or a tensor that already lives on `device` (converted to float64 there)."""
+    on_device = isinstance(A, torch.Tensor)
     if metric != "cosine" or not _use_gpu(device, A.shape[0]):
-        return _scipy_cdist(A, B, metric=metric)
+        return _scipy_cdist(A.cpu().numpy() if on_device else A, B, metric=metric)
     lib = ffi.load()
-    Ad = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(device)
+    if on_device:
+        Ad = A.to(device=device, dtype=torch.float64).contiguous()
+    else:
+        Ad = torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(device)
     Bd = torch.from_numpy(np.ascontiguousarray(B, dtype=np.float64)).to(device)
     out = torch.empty((A.shape[0], B.shape[0]), dtype=torch.float64, device=device)
     norms = torch.empty(A.shape[0] + B.shape[0], dtype=torch.float64, device=device)

@@ -331,7 +331,7 @@ class SpeakerDiarization(Pipeline):
         hard, _, centroids = self.clustering(
             embeddings=front.embeddings, segmentations=front.segmentations, num_clusters=num_speakers,
             min_clusters=min_speakers, max_clusters=max_speakers, file=front.file, frames=self._frames,
-            num_clean_frames=front.clean)
+            num_clean_frames=front.clean, device_embeddings=front.dev_emb)
         return hard, centroids
 
     def _back_end(self, front: _FrontEnd, hard_clusters: np.ndarray, centroids: Optional[np.ndarray],
