@@ -6,6 +6,10 @@ MI355X guide prescribes).  FETCH_SIZE / WRITE_SIZE are in KiB units; on gfx950 F
 of the bytes of wide coalesced reads -> doubled (both raw and corrected numbers are written)."""
 import collections, csv, glob, json, sys
 
+# kernels that one launcher (= one profiler scope / bench.py roofline entry) dispatches between: folded into the
+# launcher's name, the per-kernel split kept under "_split"
+ALIASES = {"k_conv3x3_wino32": "k_conv3x3_wino", "k_linkage_centroid_mw": "k_linkage_centroid"}
+
 def load(d, name):
     acc = collections.defaultdict(lambda: [0.0, set()])
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -28,5 +32,19 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"launches": n, "fetch_size_kib_per_launch_raw": f / max(nf, 1),
               "write_size_kib_per_launch_raw": w / max(nw, 1),
               "hbm_bytes_per_launch": round((2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024)}
+for src, dst in ALIASES.items():
+    if src not in out:
+        continue
+    a, b = out.pop(src), out.get(dst)
+    if b is None:
+        out[dst] = a
+        continue
+    n = a["launches"] + b["launches"]
+    merged = {"launches": n}
+    for key in ("fetch_size_kib_per_launch_raw", "write_size_kib_per_launch_raw", "hbm_bytes_per_launch"):
+        merged[key] = (a[key] * a["launches"] + b[key] * b["launches"]) / n
+    merged["hbm_bytes_per_launch"] = round(merged["hbm_bytes_per_launch"])
+    merged["_split"] = {**b.pop("_split", {}), dst: b, src: a}
+    out[dst] = merged
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
