@@ -320,6 +320,12 @@ int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D,
 size_t pa_linkage_workspace_bytes(int n);
 int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t workspace_bytes,
                             void* stream);
+/* The same merge with a placement hint: `alone` != 0 says that nothing else competes for the GPU while it runs (one
+ * file applied on its own, the last file of a batch), and the merge of one audio-hour (6 000 <= n < 12 000) then
+ * spreads its O(n) pass over 8 workgroups of one XCD (183 instead of 195 ms at n = 7 176); beside another file's
+ * front end one workgroup disturbs less.  Results are identical either way. */
+int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, size_t workspace_bytes, int alone,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Frame-domain stages (uint8 hard segmentations in, per-frame decisions out).  Replace the Python

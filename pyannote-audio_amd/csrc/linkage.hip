@@ -772,9 +772,11 @@ size_t pa_linkage_workspace_bytes(int n) {
 }
 
 // number of workgroups of the merge kernel: PA_LINKAGE_WGS overrides (1 = the single-workgroup kernel)
-static int lk_num_workgroups(int n) {
+static int lk_num_workgroups(int n, int alone) {
   const char* e = getenv("PA_LINKAGE_WGS");
   if (e != nullptr && atoi(e) >= 1) return atoi(e) > 32 ? 32 : atoi(e);
+  // `alone`: the caller knows that no front end runs beside this merge (a single file, the last file of a batch)
+  if (alone && n >= 6000 && n < 12000) return 8;
   // measured: the split pass wins when the O(N) pass dominates the merge.  On the joint clustering of REAL
   // embeddings (profiles/r3_joint_scale.txt) 16 workgroups take 0.92 -> 0.78 s at N = 14 k (8 workgroups: 0.72 s),
   // 3.59 -> 2.02 s at 29 k, 14.2 -> 6.7 s at 57 k; on the 4-blob synthetic set of tools/time_linkage.py, which needs
@@ -786,8 +788,16 @@ static int lk_num_workgroups(int n) {
 }
 
 // D: condensed distance matrix (n*(n-1)/2 doubles), OVERWRITTEN.  Z: (n-1, 4) doubles, SciPy layout.
+int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, size_t workspace_bytes, int alone,
+                               void* stream);
+
 int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t workspace_bytes,
                             void* stream) {
+  return pa_linkage_centroid_f64_ex(D, n, Z, workspace, workspace_bytes, 0, stream);
+}
+
+int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, size_t workspace_bytes, int alone,
+                               void* stream) {
   if (n < 2) return 0;
   PA_REQUIRE(workspace_bytes >= pa_linkage_workspace_bytes(n), "pa_linkage_centroid_f64: workspace too small");
   const size_t ni = pa::lk_align(sizeof(int) * (size_t)n), nd = pa::lk_align(sizeof(double) * (size_t)n);
@@ -806,7 +816,7 @@ int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t
   hipStream_t st = (hipStream_t)stream;
   // the merge loop is O(N^2) memory traffic in total; algorithmic bytes ~ 3 rows of 8*N per merge
   pa::ProfScope prof("k_linkage_centroid", stream, 9.0 * n * (double)n, 24.0 * n * (double)n);
-  const int G = lk_num_workgroups(n);
+  const int G = lk_num_workgroups(n, alone);
   if (G > 1) {
     if (hipMemsetAsync(shared, 0, sizeof(pa::LkShared), st) != hipSuccess) return 1;
     const size_t lds_heap = ((size_t)(n - 1) * 12 + 15) & ~(size_t)15;

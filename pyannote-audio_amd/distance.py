@@ -7,6 +7,9 @@ reproduce that summation order with explicit `__dmul_rn/__dadd_rn` (see csrc/clu
 problems stay in SciPy: the launch + copy overhead exceeds the work."""
 from __future__ import annotations
 
+import contextlib
+import threading
+
 import numpy as np
 import torch
 from scipy.spatial.distance import cdist as _scipy_cdist
@@ -44,6 +47,21 @@ def pdist_euclidean(X: np.ndarray, device=None) -> np.ndarray:
     return out.cpu().numpy()
 
 
+_hint = threading.local()
+
+
+@contextlib.contextmanager
+def device_to_ourselves():
+    """Inside this block the calling thread promises that nothing else keeps the GPU busy (one file applied on its
+    own, the last file of a batch): `linkage_centroid` may then spread the merge over several workgroups."""
+    previous = getattr(_hint, "alone", False)
+    _hint.alone = True
+    try:
+        yield
+    finally:
+        _hint.alone = previous
+
+
 @ffi.on_device(lambda X, device: device)
 def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") entirely on the GPU:
@@ -57,8 +75,9 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     ffi.check(lib.pa_pdist_f64(ffi.ptr(Xd), n, X.shape[1], ffi.ptr(cond), ffi.stream()), "pa_pdist_f64")
     Z = torch.empty((n - 1, 4), dtype=torch.float64, device=device)
     ws = torch.empty(lib.pa_linkage_workspace_bytes(n), dtype=torch.uint8, device=device)
-    ffi.check(lib.pa_linkage_centroid_f64(ffi.ptr(cond), n, ffi.ptr(Z), ffi.ptr(ws), ws.numel(),
-                                          ffi.stream()), "pa_linkage_centroid_f64")
+    ffi.check(lib.pa_linkage_centroid_f64_ex(ffi.ptr(cond), n, ffi.ptr(Z), ffi.ptr(ws), ws.numel(),
+                                             1 if getattr(_hint, "alone", False) else 0, ffi.stream()),
+              "pa_linkage_centroid_f64")
     global last_linkage_stats
     last_linkage_stats = ws[-64:].view(torch.int64).cpu().numpy()   # development counters
     return Z.cpu().numpy()

@@ -174,6 +174,7 @@ _OPTIONAL: list[tuple] = [
     ("pa_cdist_cosine_f64", [c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
     ("pa_linkage_workspace_bytes", [C.c_int], C.c_size_t),
     ("pa_linkage_centroid_f64", [c_fp, C.c_int, c_fp, c_fp, C.c_size_t, c_fp], C.c_int),
+    ("pa_linkage_centroid_f64_ex", [c_fp, C.c_int, c_fp, c_fp, C.c_size_t, C.c_int, c_fp], C.c_int),
     ("pa_seg_chunk_stats", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
     ("pa_embedding_masks", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_speaker_count", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp], C.c_int),

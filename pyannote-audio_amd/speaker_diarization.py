@@ -18,6 +18,7 @@ persistent workgroup on one CU: 15 % of a sequential step with 255 CUs idle).  `
 (parallel.set_shard) splits the chunk range of ONE file across GPUs instead."""
 from __future__ import annotations
 
+import contextlib
 import math
 import textwrap
 import threading
@@ -30,6 +31,7 @@ from typing import Any, Callable, Iterable, Iterator, List, Mapping, Optional, T
 import numpy as np
 import torch
 
+from . import distance
 from . import ffi
 from . import frames as frame_ops
 from . import parallel
@@ -415,7 +417,8 @@ class SpeakerDiarization(Pipeline):
         front = self._front_end(file, hook)
         if front.silent:
             return self._empty_output(file)
-        hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
+        with distance.device_to_ourselves():      # one file on its own: no front end runs beside its clustering
+            hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
         return self._back_end(front, hard, centroids, min_speakers, max_speakers, hook)
 
     def apply_batch(self, files: Iterable[AudioFile], num_speakers: Optional[int] = None,
@@ -461,11 +464,14 @@ class SpeakerDiarization(Pipeline):
         device = self._require_device()
         side = torch.cuda.Stream(device=device)
 
+        no_next_file = threading.Event()            # set before the LAST file's gate opens
+
         def tail(front: _FrontEnd, file_hook: Callable, bounds: tuple):
             if front.silent:
                 return self._empty_output(front.file)
             num_speakers, min_speakers, max_speakers = bounds
-            with torch.cuda.device(device), torch.cuda.stream(side):
+            alone = distance.device_to_ourselves() if no_next_file.is_set() else contextlib.nullcontext()
+            with torch.cuda.device(device), torch.cuda.stream(side), alone:
                 hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
                 out = self._back_end(front, hard, centroids, min_speakers, max_speakers, file_hook)
                 side.synchronize()
@@ -511,7 +517,8 @@ class SpeakerDiarization(Pipeline):
                     gate = threading.Event()
                     in_flight = (file, pool.submit(tail_timed, front, file_hook, line, bounds, gate))
                 if in_flight is not None:
-                    gate.set()                                  # no next file
+                    no_next_file.set()
+                    gate.set()
                     yield in_flight[0], in_flight[1].result()
             finally:
                 if gate is not None:
