@@ -128,3 +128,29 @@ def test_unplaced_clustering_object_raises():
         {"method": "centroid", "min_cluster_size": 2, "threshold": 0.7})
     with pytest.raises(RuntimeError, match="no device set"):
         clu(embeddings=emb, segmentations=seg, min_clusters=1, max_clusters=np.inf)
+
+
+def test_merge_placement_hint_is_thread_local_and_nests():
+    """`distance.device_to_ourselves()` (one file on its own / last file of a batch -> the dendrogram merge may use
+    several workgroups) only marks the calling thread and restores the previous state on exit."""
+    import threading
+    from pyannote_audio_amd import distance
+
+    def alone():
+        return getattr(distance._hint, "alone", False)
+
+    assert not alone()
+    seen = {}
+    with distance.device_to_ourselves():
+        assert alone()
+        t = threading.Thread(target=lambda: seen.setdefault("other", alone()))
+        t.start()
+        t.join()
+        with distance.device_to_ourselves():
+            assert alone()
+        assert alone()
+        with pytest.raises(RuntimeError):
+            with distance.device_to_ourselves():
+                raise RuntimeError("boom")
+        assert alone()
+    assert not alone() and seen == {"other": False}
