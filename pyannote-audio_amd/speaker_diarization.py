@@ -21,10 +21,8 @@ from __future__ import annotations
 import contextlib
 import math
 import textwrap
-import threading
 import time
 import warnings
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Any, Callable, Iterable, Iterator, List, Mapping, Optional, Tuple
 
@@ -42,6 +40,7 @@ from .diarization import optimal_mapping, set_num_speakers, to_annotation
 from .inference import Inference
 from .model import Model
 from .pipeline import ParamDict, Pipeline, Uniform
+from .pipelining import pipelined
 from .speaker_verification import PipelineModel, PretrainedSpeakerEmbedding, get_model
 
 
@@ -464,19 +463,6 @@ class SpeakerDiarization(Pipeline):
         device = self._require_device()
         side = torch.cuda.Stream(device=device)
 
-        no_next_file = threading.Event()            # set before the LAST file's gate opens
-
-        def tail(front: _FrontEnd, file_hook: Callable, bounds: tuple):
-            if front.silent:
-                return self._empty_output(front.file)
-            num_speakers, min_speakers, max_speakers = bounds
-            alone = distance.device_to_ourselves() if no_next_file.is_set() else contextlib.nullcontext()
-            with torch.cuda.device(device), torch.cuda.stream(side), alone:
-                hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
-                out = self._back_end(front, hard, centroids, min_speakers, max_speakers, file_hook)
-                side.synchronize()
-            return out
-
         # The dendrogram merge of file i is ONE workgroup that owns a CU for ~0.2 s per audio-hour while the
         # front end of file i+1 runs.  The persistent convolution kernels CLAIM their tiles at run time
         # (csrc/common.h: TileQueue), so the workgroups that cannot be placed beside the merge merely find
@@ -484,45 +470,40 @@ class SpeakerDiarization(Pipeline):
         # convolution launch under the merge took 1.6x as long (tools/probes/interference_probe.py).
         # The SEGMENTATION kernels are ordinary one-round grids (k_lstm_rec: 450 workgroups that live for the whole
         # launch): the one that shares its CU with the merge is slowed and the launch ends with it (+26 %, stage
-        # +20 ms per audio-hour, tools/batch_prof.py).  So the tail of file i is GATED: it starts when the
-        # segmentation stage of file i+1 has left the device (or there is no next file) and overlaps only the
-        # embedding stage.
+        # +20 ms per audio-hour, tools/batch_prof.py).  So the tail of file i is GATED (pipelining.pipelined): it
+        # starts when the segmentation stage of file i+1 has left the device (or there is no next file) and
+        # overlaps only the embedding stage.
         t_batch = time.perf_counter()
         self.batch_timeline = []               # per file: host-clock offsets (s) of the stage boundaries
 
-        def tail_timed(front: _FrontEnd, file_hook: Callable, line: dict, bounds: tuple, gate: threading.Event):
-            line["tail_start"] = time.perf_counter() - t_batch
-            if not front.silent:
-                gate.wait(timeout=self.TAIL_GATE_TIMEOUT)
+        def front_of(item, release: Callable):
+            file, bounds = item
+            file_hook = self.setup_hook(file, hook=hook)
+            line = {"front_start": time.perf_counter() - t_batch}
+            front = self._front_end(file, file_hook, after_segmentation=release)
+            line.update({name: stamp - t_batch for name, stamp in front.marks[1:]})
+            line.update({name + "_queued": stamp - t_batch for name, stamp in front.enqueued.items()})
+            line["submit"] = time.perf_counter() - t_batch
+            self.batch_timeline.append(line)
+            return front, file_hook, line, bounds
+
+        def tail_of(state, alone: bool):
+            front, file_hook, line, (num_speakers, min_speakers, max_speakers) = state
             line["tail_released"] = time.perf_counter() - t_batch
-            out = tail(front, file_hook, bounds)
+            if front.silent:
+                out = self._empty_output(front.file)
+            else:
+                # `alone`: the last file's merge has the GPU to itself (distance.device_to_ourselves)
+                hint = distance.device_to_ourselves() if alone else contextlib.nullcontext()
+                with torch.cuda.device(device), torch.cuda.stream(side), hint:
+                    hard, centroids = self._cluster_one(front, num_speakers, min_speakers, max_speakers)
+                    out = self._back_end(front, hard, centroids, min_speakers, max_speakers, file_hook)
+                    side.synchronize()
             line["tail_done"] = time.perf_counter() - t_batch
             return out
 
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            in_flight = gate = None
-            try:
-                for file, bounds in zip(files, all_bounds):
-                    file_hook = self.setup_hook(file, hook=hook)
-                    line = {"front_start": time.perf_counter() - t_batch}
-                    front = self._front_end(file, file_hook, after_segmentation=gate.set if gate else None)
-                    if gate is not None:
-                        gate.set()
-                    line.update({name: stamp - t_batch for name, stamp in front.marks[1:]})
-                    line.update({name + "_queued": stamp - t_batch for name, stamp in front.enqueued.items()})
-                    self.batch_timeline.append(line)
-                    if in_flight is not None:
-                        yield in_flight[0], in_flight[1].result()
-                    line["submit"] = time.perf_counter() - t_batch
-                    gate = threading.Event()
-                    in_flight = (file, pool.submit(tail_timed, front, file_hook, line, bounds, gate))
-                if in_flight is not None:
-                    no_next_file.set()
-                    gate.set()
-                    yield in_flight[0], in_flight[1].result()
-            finally:
-                if gate is not None:
-                    gate.set()                                  # (a failing front end must not strand the tail)
+        for (file, _), out in pipelined(zip(files, all_bounds), front_of, tail_of, self.TAIL_GATE_TIMEOUT):
+            yield file, out
 
     def _apply_jointly(self, files: List[dict], bounds, hook, device: torch.device):
         """front end per file; records of all files of all ranks gathered on the device; ONE clustering
@@ -543,31 +524,18 @@ class SpeakerDiarization(Pipeline):
         device = self._require_device()
         side = torch.cuda.Stream(device=device)
 
-        def finish(job, gate: threading.Event):
-            gate.wait(timeout=self.TAIL_GATE_TIMEOUT)   # (as in apply_batch: not beside a segmentation stage)
+        def gather(group, release: Callable):
+            return self._joint_gather([Audio.validate_file(f) for f in group], hook, device,
+                                      after_segmentation=release)
+
+        def finish(job, alone: bool):        # (as in apply_batch: not beside a segmentation stage)
             with torch.cuda.device(device), torch.cuda.stream(side):
                 out = list(self._joint_finish(job, bounds))
                 side.synchronize()
             return out
 
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            in_flight = gate = None
-            try:
-                for group in groups:
-                    job = self._joint_gather([Audio.validate_file(f) for f in group], hook, device,
-                                             after_segmentation=gate.set if gate else None)
-                    if gate is not None:
-                        gate.set()
-                    if in_flight is not None:
-                        yield in_flight.result()
-                    gate = threading.Event()
-                    in_flight = pool.submit(finish, job, gate)
-                if in_flight is not None:
-                    gate.set()
-                    yield in_flight.result()
-            finally:
-                if gate is not None:
-                    gate.set()
+        for _, out in pipelined(groups, gather, finish, self.TAIL_GATE_TIMEOUT):
+            yield out
 
     def _joint_gather(self, files: List[dict], hook, device: torch.device,
                       after_segmentation: Optional[Callable] = None) -> dict:
