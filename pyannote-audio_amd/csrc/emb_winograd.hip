@@ -507,7 +507,11 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
 //     Two workgroup barriers per pair of tiles.
 //   * tiles are claimed per half (TileQueue); the claim is issued in a PREPARE step, resolved in the next
 //     COMPUTE step and published by that step's closing barrier.
-// One workgroup per CU (152 KB of LDS), two waves per SIMD as before.
+// One workgroup per CU (152 KB of LDS), two waves per SIMD as before.  Same arithmetic in the same order as the generic
+// kernel: bit-identical outputs.  Measured (B = 512, profiles/r3_wino32_ab.txt): 80x998x32 3.83 -> 3.62 ms without
+// residual (0.59 of peak), 4.35 -> 4.13 ms with (0.52) -- less than the schedule promises, because the two halves
+// share every SIMD and f32 MFMAs issue at the vector rate: SIMD time is the SUM of both halves' issue cycles.
+// PA_WINO32=0 (environment) selects the generic kernel for an A/B.
 // =============================================================================================
 template <bool HAS_R>
 __global__ __launch_bounds__(512) void k_conv3x3_wino32(
