@@ -76,6 +76,12 @@ typedef struct pa_seg_weights {
 /* frames per chunk for `num_samples` (SincNet.num_frames, models/blocks/sincnet.py:82-107) */
 int pa_seg_num_frames(int num_samples, int sinc_stride);
 size_t pa_seg_workspace_bytes(const pa_seg_weights* w, int num_chunks, int num_samples);
+/* The same for callers that know the chunk stride: identical to pa_seg_workspace_bytes unless the EXPERIMENTAL
+ * shared sinc layer is switched on (environment PA_SEG_SHARED_SINC=1; overlapping chunks whose stride is a
+ * multiple of 10 samples), which needs 320 B per span position more.  pa_seg_forward falls back to the per-chunk
+ * layer when the workspace it is given is the smaller one. */
+size_t pa_seg_workspace_bytes_strided(const pa_seg_weights* w, int num_chunks, int num_samples,
+                                      int64_t chunk_stride);
 /* Chunk b is wav[b*chunk_stride : b*chunk_stride + num_samples], zero beyond wav_len
  * (Inference.slide's unfold + zero-padded last chunk, core/inference.py:261-278).
  * logp: (num_chunks, F, num_classes) log-probabilities or NULL;
@@ -90,6 +96,15 @@ int pa_row_stats(const float* x, long row_stride, long total_len, int rows, int 
 int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, int N, int stride,
                      const float* mean, const float* rstd, float gamma, float beta,
                      const float* filt_packed, float* out, void* stream);
+/* EXPERIMENTAL (not yet run on hardware; off unless PA_SEG_SHARED_SINC=1): the sinc layer once per span of
+ * overlapping chunks.  pa_sinc_fir_span: S (80, Pc) = raw filter outputs of wav[0, span) (zeros past wav_len),
+ * Pc = (span - 251) / 10 + 1.  pa_sinc_fix_pool: chunk b starts `positions_per_chunk_step` positions after chunk
+ * b - 1; per-chunk affine fix-up of the waveform InstanceNorm, magnitude, maxpool3 -> out (B, 80, P) exactly what
+ * pa_sinc_fir_pool writes (up to float rounding: 1e-6 of the peak); tap_sums: 80 floats of scratch. */
+int pa_sinc_fir_span(const float* wav, long wav_len, long span, const float* filt_packed, float* S, void* stream);
+int pa_sinc_fix_pool(const float* S, long Pc, int positions_per_chunk_step, int B, int P, const float* mean,
+                     const float* rstd, float gamma, float beta, const float* filt_packed, float* tap_sums,
+                     float* out, void* stream);
 int pa_conv5_pool(const float* xin, int B, int cin, int Lin, const float* in_mean,
                   const float* in_rstd, const float* gam, const float* bet, const float* w_packed,
                   const float* bias64, float* out, void* stream);

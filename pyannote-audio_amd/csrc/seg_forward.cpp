@@ -2,6 +2,7 @@
 // Replaces PyanNet.forward + hard Powerset conversion (PyanNet.py:211-240, powerset.py:115-140).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/pyannote_amd.h"
 
@@ -17,11 +18,22 @@ struct SegPlan {
   // offsets in floats
   size_t wav_mean, wav_rstd, s1, st1m, st1r, s2, st2m, st2r, s3, st3m, st3r, x0, xproj, h0, h1, l0, l1,
       total;
+  // the sinc layer once per span of overlapping chunks (EXPERIMENTAL, PA_SEG_SHARED_SINC=1): raw filter outputs
+  // of the whole span + the tap sums
+  long span, span_pos;
+  size_t span_s, tap_sums;
 };
+
+// EXPERIMENTAL, off by default: see seg_frontend.hip (k_sinc_fix_pool)
+inline bool shared_sinc_wanted(const pa_seg_weights* w, int B, int N, int64_t chunk_stride) {
+  const char* e = getenv("PA_SEG_SHARED_SINC");
+  return e != nullptr && atoi(e) == 1 && w->sinc_stride == 10 && B >= 2 && chunk_stride > 0 && chunk_stride < N &&
+         chunk_stride % 10 == 0 && (int64_t)(B - 1) * chunk_stride + N <= 0x7fffffffLL;
+}
 
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-bool make_plan(const pa_seg_weights* w, int B, int N, SegPlan* p) {
+bool make_plan(const pa_seg_weights* w, int B, int N, int64_t chunk_stride, SegPlan* p) {
   p->B = B;
   p->N = N;
   p->L1 = (N - 251) / w->sinc_stride + 1;
@@ -57,6 +69,14 @@ bool make_plan(const pa_seg_weights* w, int B, int N, SegPlan* p) {
   p->h1 = take((size_t)p->M * 256);
   p->l0 = take((size_t)p->M * 128);
   p->l1 = take((size_t)p->M * 128);
+  p->span = p->span_pos = 0;
+  p->span_s = p->tap_sums = 0;
+  if (shared_sinc_wanted(w, B, N, chunk_stride)) {
+    p->span = (long)(B - 1) * chunk_stride + N;
+    p->span_pos = (p->span - 251) / 10 + 1;
+    p->span_s = take((size_t)80 * p->span_pos);
+    p->tap_sums = take(80);
+  }
   p->total = o;
   return true;
 }
@@ -76,10 +96,15 @@ int pa_seg_num_frames(int num_samples, int sinc_stride) {
   return n;
 }
 
-size_t pa_seg_workspace_bytes(const pa_seg_weights* w, int num_chunks, int num_samples) {
+size_t pa_seg_workspace_bytes_strided(const pa_seg_weights* w, int num_chunks, int num_samples,
+                                      int64_t chunk_stride) {
   SegPlan p;
-  if (!make_plan(w, num_chunks, num_samples, &p)) return 0;
+  if (!make_plan(w, num_chunks, num_samples, chunk_stride, &p)) return 0;
   return p.total * sizeof(float);
+}
+
+size_t pa_seg_workspace_bytes(const pa_seg_weights* w, int num_chunks, int num_samples) {
+  return pa_seg_workspace_bytes_strided(w, num_chunks, num_samples, num_samples);
 }
 
 int pa_seg_forward(const pa_seg_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
@@ -87,9 +112,13 @@ int pa_seg_forward(const pa_seg_weights* w, const float* wav, int64_t wav_len, i
                    size_t workspace_bytes, void* stream) {
   if (num_chunks <= 0) return 0;
   SegPlan p;
-  if (!make_plan(w, num_chunks, num_samples, &p)) {
+  if (!make_plan(w, num_chunks, num_samples, chunk_stride, &p)) {
     pa::set_error("pa_seg_forward: chunk of %d samples is too short for SincNet", num_samples);
     return 3;
+  }
+  if (p.span_pos > 0 && workspace_bytes < p.total * sizeof(float)) {
+    // a workspace sized without the stride (pa_seg_workspace_bytes): the per-chunk sinc layer
+    make_plan(w, num_chunks, num_samples, num_samples, &p);
   }
   if (w->lstm_hidden != 128 || !w->lstm_bidir || w->lstm_layers < 1 ||
       w->lstm_layers > PA_MAX_LSTM_LAYERS || w->num_linear > PA_MAX_LINEAR ||
@@ -113,8 +142,15 @@ int pa_seg_forward(const pa_seg_weights* w, const float* wav, int64_t wav_len, i
 
   // SincNet (models/blocks/sincnet.py:163-184)
   RUN(pa_row_stats(wav, chunk_stride, wav_len, B, p.N, 1e-5f, ws + p.wav_mean, ws + p.wav_rstd, stream));
-  RUN(pa_sinc_fir_pool(wav, wav_len, chunk_stride, B, p.N, w->sinc_stride, ws + p.wav_mean,
-                       ws + p.wav_rstd, w->wav_gamma, w->wav_beta, w->sinc_filt, ws + p.s1, stream));
+  if (p.span_pos > 0) {
+    RUN(pa_sinc_fir_span(wav, wav_len, p.span, w->sinc_filt, ws + p.span_s, stream));
+    RUN(pa_sinc_fix_pool(ws + p.span_s, p.span_pos, (int)(chunk_stride / 10), B, p.P1, ws + p.wav_mean,
+                         ws + p.wav_rstd, w->wav_gamma, w->wav_beta, w->sinc_filt, ws + p.tap_sums, ws + p.s1,
+                         stream));
+  } else {
+    RUN(pa_sinc_fir_pool(wav, wav_len, chunk_stride, B, p.N, w->sinc_stride, ws + p.wav_mean,
+                         ws + p.wav_rstd, w->wav_gamma, w->wav_beta, w->sinc_filt, ws + p.s1, stream));
+  }
   RUN(pa_row_stats(ws + p.s1, p.P1, (long)B * 80 * p.P1, B * 80, p.P1, 1e-5f, ws + p.st1m, ws + p.st1r,
                    stream));
   RUN(pa_conv5_pool(ws + p.s1, B, 80, p.P1, ws + p.st1m, ws + p.st1r, w->norm0, w->norm0 + 80,

@@ -63,6 +63,10 @@ constexpr int SINC_XS = 30 * SINC_PT + 256;        // staged samples (>= 30*PT +
 constexpr int SINC_OS = SINC_PT + 4;               // out-tile row stride in LDS
 constexpr int SINC_T = 640;                        // threads
 
+// RAW = true (the sinc layer ONCE for a whole span of overlapping chunks, see k_sinc_fix_pool): no normalisation on
+// load, no magnitude, no pooling -- MFMA row i is convolution position i, `P` counts convolution positions and `out`
+// is (80, P) raw filter outputs of the span [wav, wav + N).
+template <bool RAW>
 __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
     const float* __restrict__ wav, long wav_len, long chunk_stride, int N, int stride, int P,
     const float* __restrict__ mean, const float* __restrict__ rstd, float gamma, float beta,
@@ -74,12 +78,14 @@ __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
   const int p0 = blockIdx.x * SINC_PT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = (tid >> 6) % 5, half = (tid >> 6) / 5;   // filter tile, half of the positions
-  constexpr int STR = 10;          // SincNet stride (checked by the host wrapper)
-  constexpr int PS = 3 * STR;      // sample advance per pooled output
+  constexpr int STR = 10;                   // SincNet stride (checked by the host wrapper)
+  constexpr int PS = RAW ? STR : 3 * STR;   // sample advance per output row (pooled: three positions per row)
+  constexpr int XS = RAW ? STR * SINC_PT + 256 : SINC_XS;   // staged samples
 
   // stage normalised samples [PS*p0, PS*p0 + nstage)
   const long cbase = (long)b * chunk_stride;
-  const float mu = mean[b], rs = rstd[b] * gamma;
+  const float mu = RAW ? 0.f : mean[b], rs = RAW ? 1.f : rstd[b] * gamma;
+  if (RAW) beta = 0.f;
   // (all loads of a thread are issued before the first use: as a plain loop the compiler waits for every load
   //  in turn)
   {
@@ -89,12 +95,12 @@ __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
     for (int k = 0; k < NS; ++k) {
       const int i = tid + SINC_T * k;
       const long g = cbase + PS * p0 + i;
-      raw[k] = (i < SINC_XS && PS * p0 + i < N && g < wav_len) ? wav[g] : 0.f;
+      raw[k] = (i < XS && PS * p0 + i < N && g < wav_len) ? wav[g] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const int i = tid + SINC_T * k;
-      if (i < SINC_XS) xs[i] = PS * p0 + i < N ? (raw[k] - mu) * rs + beta : 0.f;
+      if (i < XS) xs[i] = PS * p0 + i < N ? (raw[k] - mu) * rs + beta : 0.f;
     }
   }
   // filter taps -> registers (B operand)
@@ -111,13 +117,15 @@ __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
 #pragma unroll
     for (int kt = 0; kt < 63; ++kt) {
       a0 = MFMA16(xp[4 * kt], fb[kt], a0);
-      a1 = MFMA16(xp[4 * kt + STR], fb[kt], a1);
-      a2 = MFMA16(xp[4 * kt + 2 * STR], fb[kt], a2);
+      if (!RAW) {
+        a1 = MFMA16(xp[4 * kt + STR], fb[kt], a1);
+        a2 = MFMA16(xp[4 * kt + 2 * STR], fb[kt], a2);
+      }
     }
-    // lane holds filter 16w + i16 (column), pooled rows 16*grp + 4*kq + r
+    // lane holds filter 16w + i16 (column), output rows 16*grp + 4*kq + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = fmaxf(fmaxf(fabsf(a0[r]), fabsf(a1[r])), fabsf(a2[r]));
+      const float v = RAW ? a0[r] : fmaxf(fmaxf(fabsf(a0[r]), fabsf(a1[r])), fabsf(a2[r]));
       os[(16 * w + i16) * SINC_OS + 16 * grp + 4 * kq + r] = v;
     }
   }
@@ -126,6 +134,44 @@ __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
   for (int i = tid; i < 80 * SINC_PT; i += SINC_T) {
     const int c = i / SINC_PT, p = i % SINC_PT;
     if (p < np) out[((long)b * 80 + c) * P + p0 + p] = os[c * SINC_OS + p];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sinc layer once per SPAN of overlapping chunks (EXPERIMENTAL: written after round 3's GPU budget was spent,
+// numerics cleared on the CPU with tools/probes/shared_sinc_numerics.py, NOT yet run on hardware; off unless
+// PA_SEG_SHARED_SINC=1, pa_seg_forward).  Chunks of the sliding window start at multiples of Q = chunk_stride /
+// 10 convolution positions and the waveform InstanceNorm is affine, so with S = sinc(raw span), S1[f] = sum of
+// the taps of filter f and g = rstd * gamma:
+//     sinc((x - mu) g + beta)[f][q] = g (S[f][c Q + q] - mu S1[f]) + beta S1[f]
+// k_sinc_tapsum: S1 from the packed B-operand image.  k_sinc_fix_pool: the fix-up + |.| + maxpool3 of chunk b,
+// (B, 80, P) out, as k_sinc_fir_pool<false> writes it.  grid = (ceil(P / 256), B), block = 256; a thread walks
+// the 80 filters of its pooled position (reads 12 contiguous bytes per filter, coalesced across the wave).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_sinc_tapsum(const float* __restrict__ filt, float* __restrict__ S1) {
+  const int f = threadIdx.x;
+  if (f >= 80) return;
+  double acc = 0.0;
+  for (int kt = 0; kt < 63; ++kt)
+    for (int q = 0; q < 4; ++q) acc += (double)filt[((f >> 4) * 63 + kt) * 64 + (f & 15) + 16 * q];
+  S1[f] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void k_sinc_fix_pool(const float* __restrict__ S, long Pc, int Q, int P,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float gamma, float beta,
+                                                        const float* __restrict__ S1, float* __restrict__ out) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const float mu = mean[b], g = rstd[b] * gamma;
+  const float* src = S + (long)b * Q + 3 * p;
+  float* dst = out + (long)b * 80 * P + p;
+#pragma unroll 8
+  for (int f = 0; f < 80; ++f) {
+    const float s1 = S1[f], off = beta * s1 - g * mu * s1;
+    const float* row = src + (long)f * Pc;
+    const float v0 = fabsf(fmaf(g, row[0], off)), v1 = fabsf(fmaf(g, row[1], off)), v2 = fabsf(fmaf(g, row[2], off));
+    dst[(long)f * P] = fmaxf(fmaxf(v0, v1), v2);
   }
 }
 
@@ -279,14 +325,44 @@ int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, i
   if (B <= 0 || P <= 0) return 0;
   const size_t lds = (pa::SINC_XS + 80 * pa::SINC_OS) * sizeof(float);
   // (set on every call: the attribute belongs to the current device, not to the process)
-  (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool, hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   pa::ProfScope prof("k_sinc_fir_pool", stream, 2.0 * B * 80 * 251 * (3.0 * P),
                      4.0 * B * N + 4.0 * B * 80 * P);
-  hipLaunchKernelGGL(pa::k_sinc_fir_pool, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(pa::SINC_T), lds,
+  hipLaunchKernelGGL(pa::k_sinc_fir_pool<false>, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(pa::SINC_T), lds,
                      (hipStream_t)stream, wav, wav_len, chunk_stride, N, stride, P, mean, rstd, gamma,
                      beta, filt_packed, out);
   PA_CHECK_LAUNCH("pa_sinc_fir_pool");
+  return 0;
+}
+
+// EXPERIMENTAL (see k_sinc_fix_pool).  S: (80, Pc) raw sinc outputs of the span wav[0, span) (zeros past wav_len),
+// Pc = (span - 251) / 10 + 1.
+int pa_sinc_fir_span(const float* wav, long wav_len, long span, const float* filt_packed, float* S,
+                     void* stream) {
+  if (span < 251) return 0;
+  PA_REQUIRE(span <= 0x7fffffffL, "pa_sinc_fir_span: span of %ld samples is too long", span);
+  const int Pc = (int)((span - 251) / 10 + 1);
+  const size_t lds = (pa::SINC_XS + 80 * pa::SINC_OS) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  pa::ProfScope prof("k_sinc_fir_span", stream, 2.0 * 80 * 251 * (double)Pc, 4.0 * span + 4.0 * 80 * Pc);
+  hipLaunchKernelGGL(pa::k_sinc_fir_pool<true>, dim3(pa::cdiv(Pc, pa::SINC_PT), 1), dim3(pa::SINC_T), lds,
+                     (hipStream_t)stream, wav, wav_len, 0L, (int)span, 10, Pc, (const float*)nullptr,
+                     (const float*)nullptr, 1.f, 0.f, filt_packed, S);
+  PA_CHECK_LAUNCH("pa_sinc_fir_span");
+  return 0;
+}
+
+int pa_sinc_fix_pool(const float* S, long Pc, int positions_per_chunk_step, int B, int P, const float* mean,
+                     const float* rstd, float gamma, float beta, const float* filt_packed, float* tap_sums,
+                     float* out, void* stream) {
+  if (B <= 0 || P <= 0) return 0;
+  pa::ProfScope prof("k_sinc_fix_pool", stream, 8.0 * B * 80 * 3.0 * P, 4.0 * B * 80 * 4.0 * P);
+  hipLaunchKernelGGL(pa::k_sinc_tapsum, dim3(1), dim3(128), 0, (hipStream_t)stream, filt_packed, tap_sums);
+  hipLaunchKernelGGL(pa::k_sinc_fix_pool, dim3(pa::cdiv(P, 256), B), dim3(256), 0, (hipStream_t)stream, S, Pc,
+                     positions_per_chunk_step, P, mean, rstd, gamma, beta, (const float*)tap_sums, out);
+  PA_CHECK_LAUNCH("pa_sinc_fix_pool");
   return 0;
 }
 

@@ -129,12 +129,17 @@ def load():
     lib.pa_version.restype = C.c_int
     lib.pa_seg_workspace_bytes.restype = C.c_size_t
     lib.pa_seg_workspace_bytes.argtypes = [C.POINTER(SegWeights), C.c_int, C.c_int]
+    lib.pa_seg_workspace_bytes_strided.restype = C.c_size_t
+    lib.pa_seg_workspace_bytes_strided.argtypes = [C.POINTER(SegWeights), C.c_int, C.c_int, C.c_int64]
     lib.pa_seg_num_frames.argtypes = [C.c_int, C.c_int]
     lib.pa_seg_forward.argtypes = [C.POINTER(SegWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                    c_fp, c_fp, c_fp, C.c_size_t, c_fp]
     lib.pa_row_stats.argtypes = [c_fp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp]
     lib.pa_sinc_fir_pool.argtypes = [c_fp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, c_fp, c_fp,
                                      C.c_float, C.c_float, c_fp, c_fp, c_fp]
+    lib.pa_sinc_fir_span.argtypes = [c_fp, C.c_long, C.c_long, c_fp, c_fp, c_fp]
+    lib.pa_sinc_fix_pool.argtypes = [c_fp, C.c_long, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_float, C.c_float,
+                                     c_fp, c_fp, c_fp, c_fp]
     lib.pa_conv5_pool.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                   c_fp, c_fp]
     lib.pa_norm_transpose.argtypes = [c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]

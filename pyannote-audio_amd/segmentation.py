@@ -61,7 +61,7 @@ class SegmentationEngine:
         c0 = 0
         while c0 < num_chunks:
             nb = min(self.max_chunks, num_chunks - c0)
-            need = self._workspace_bytes(lib, w, nb, num_samples)
+            need = self._workspace_bytes(lib, w, nb, num_samples, chunk_stride)
             ws = self._workspace(need)
             off = c0 * chunk_stride
             sub = wav[off:] if off < wav.numel() else wav[:0]
@@ -78,8 +78,8 @@ class SegmentationEngine:
     def frames_of(self, num_samples: int) -> int:
         return num_frames(num_samples)
 
-    def _workspace_bytes(self, lib, w, nb, num_samples):
-        return lib.pa_seg_workspace_bytes(w, nb, num_samples)
+    def _workspace_bytes(self, lib, w, nb, num_samples, chunk_stride):
+        return lib.pa_seg_workspace_bytes_strided(w, nb, num_samples, chunk_stride)
 
     def _launch(self, lib, w, wav_ptr, wav_len, chunk_stride, nb, num_samples, logp_ptr, ml_ptr, ws, F):
         return lib.pa_seg_forward(w, wav_ptr, wav_len, chunk_stride, nb, num_samples, logp_ptr, ml_ptr,
@@ -105,7 +105,7 @@ class SSeRiouSSEngine(SegmentationEngine):
     def frames_of(self, num_samples: int) -> int:
         return ffi.load().pa_sser_num_frames(self.pack.struct, num_samples)
 
-    def _workspace_bytes(self, lib, w, nb, num_samples):
+    def _workspace_bytes(self, lib, w, nb, num_samples, chunk_stride):
         return lib.pa_sser_workspace_bytes(w, nb, num_samples)
 
     def _launch(self, lib, w, wav_ptr, wav_len, chunk_stride, nb, num_samples, logp_ptr, ml_ptr, ws, F):

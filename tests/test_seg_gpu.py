@@ -1,6 +1,7 @@
 """GPU parity: HIP segmentation kernels (through the C ABI) vs the torch-CPU oracle.
 Tolerances: SURVEY.md section 8d -- log-probs rtol 1e-4 / atol 1e-5 class (fp32 re-association)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -175,3 +176,53 @@ def test_seg_forward_end_to_end(seg, gpu_device, B, N, stride):
     # reference Model.forward contract: (B,1,N) in -> (B,F,K) out
     out = eng.forward(chunks[:2].to(gpu_device))
     assert north_star_ratio(f"seg_forward_contract_N{N}", out, ref[:2]) <= 1.0
+
+
+@pytest.mark.skipif(os.environ.get("PA_TEST_SHARED_SINC") != "1",
+                    reason="EXPERIMENTAL path, not yet run on hardware (written after round 3's GPU budget was "
+                           "spent): PA_TEST_SHARED_SINC=1 python -m pytest tests/test_seg_gpu.py -m gpu -k shared_sinc")
+def test_shared_sinc_layer_matches_the_per_chunk_layer(seg, gpu_device):
+    """The sinc layer computed ONCE for a span of overlapping chunks + per-chunk affine fix-up (pa_sinc_fir_span,
+    pa_sinc_fix_pool; pa_seg_forward with PA_SEG_SHARED_SINC=1) against the per-chunk layer: the pooled magnitudes
+    within the element-wise tolerance of the oracle, and the whole forward within it too (the CPU study
+    tools/probes/shared_sinc_numerics.py: log-probabilities move by 2.5e-5, no hard decision changes)."""
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.segmentation import SegmentationEngine
+    lib = ffi.load()
+    model, pack, _ = seg
+    sn = model.sincnet
+    w = pack.struct
+    dev = gpu_device
+    N, STEP, B = 160000, 16000, 7
+    x = _wave(1, (B - 1) * STEP + N - 4000)[0, 0]          # the last chunk is zero padded
+    chunks = torch.stack([F.pad(x[c * STEP: c * STEP + N], (0, max(0, c * STEP + N - x.numel()))) for c in range(B)])
+    with torch.inference_mode():
+        p1 = sn.pool1d[0](torch.abs(sn.conv1d[0](sn.wav_norm1d(chunks.unsqueeze(1)))))
+    xd = x.contiguous().to(dev)
+    st = ffi.stream()
+    mean = torch.empty(B, device=dev); rstd = torch.empty(B, device=dev)
+    ffi.check(lib.pa_row_stats(ffi.ptr(xd), STEP, xd.numel(), B, N, 1e-5, ffi.ptr(mean), ffi.ptr(rstd), st))
+    span = (B - 1) * STEP + N
+    Pc = (span - 251) // 10 + 1
+    S = torch.empty(80, Pc, device=dev)
+    taps = torch.empty(80, device=dev)
+    P1 = p1.shape[-1]
+    s1 = torch.zeros(B, 80, P1, device=dev)
+    ffi.check(lib.pa_sinc_fir_span(ffi.ptr(xd), xd.numel(), span, w.sinc_filt, ffi.ptr(S), st))
+    ffi.check(lib.pa_sinc_fix_pool(ffi.ptr(S), Pc, STEP // 10, B, P1, ffi.ptr(mean), ffi.ptr(rstd), w.wav_gamma,
+                                   w.wav_beta, w.sinc_filt, ffi.ptr(taps), ffi.ptr(s1), st))
+    assert north_star_ratio("shared_sinc_pool", s1, p1) <= 1.0
+    engine = SegmentationEngine(pack)
+    outs = {}
+    for flag in ("0", "1"):
+        os.environ["PA_SEG_SHARED_SINC"] = flag
+        try:
+            logp, ml = engine.forward_strided(xd, STEP, B, N)
+            outs[flag] = (logp.cpu(), ml.cpu())
+        finally:
+            os.environ.pop("PA_SEG_SHARED_SINC", None)
+    assert north_star_ratio("shared_sinc_logp", outs["1"][0], outs["0"][0]) <= 1.0
+    top2 = outs["0"][0].topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > 1e-4
+    same = (outs["1"][1] == outs["0"][1]).all(dim=-1)
+    assert bool((same | ~decided).all())
