@@ -61,6 +61,12 @@
 #endif
 // (nt / "streaming" cache-policy bits on the patch DMA, the residual loads or the stores: measured neutral to
 //  10-25 % slower, profiles/r3_wino_cache_policy.txt -- every access keeps the default policy)
+#ifndef PA_WINO_RPIN
+#define PA_WINO_RPIN 1
+#endif
+#ifndef PA_WINO_REFRESH   // 128-channel residual kernel with pinned residual loads: OFF until it has been timed
+#define PA_WINO_REFRESH 0
+#endif
 #ifndef PA_WINO_RTOUCH
 #define PA_WINO_RTOUCH 1
 #endif
@@ -283,7 +289,7 @@ __device__ __forceinline__ void wino_out_offsets(int (&off)[4], const WinoTile& 
 // at 16 l) by LDS-DMA pieces issued in front of the tile's LAST MFMA run, so that their HBM latency hides under
 // that run without holding registers (the kernel has none to spare: a register version spilled 20-30 VGPRs);
 // the second group's loads are issued here and hide under the first group's inverse transform.
-template <bool HAS_R, bool PRE = false, bool PRE0 = false>
+template <bool HAS_R, bool PRE = false, bool PRE0 = false, bool PIN = false>
 __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
                                               int COUT, const float* __restrict__ shift,
                                               const float* __restrict__ R, float* __restrict__ Y,
@@ -315,6 +321,10 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
         rv[cg][e] = HAS_R ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off[e] + 64 * cg, 0, 0))
                           : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  // all residual loads leave BEFORE the inverse transform: left alone, the scheduler sinks some of them next to
+  // their first use (seen in the 4 x 64-pixel instantiation: two loads each followed by a full vmcnt(0) wait, i.e.
+  // two exposed HBM latencies per tile)
+  if (HAS_R && PIN) __builtin_amdgcn_sched_barrier(0);
   const float lo = relu ? 0.f : -__builtin_inff();
   const f32x4 lo4 = {lo, lo, lo, lo};
 #pragma unroll
@@ -375,11 +385,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   int q = *s_next;
   int ahead = 0;
   const int x0_last = (tiles_w - 1) * 32 * TCG;
+  // The 4 x 64-pixel residual instantiation (128-channel layers) only: the compiler sank two of its eight residual
+  // loads next to their first use, each behind a full `s_waitcnt vmcnt(0)` -- three exposed HBM latencies per tile
+  // (ISA of round 3's measured build; its twin without residual is 10 % faster per launch).  There the loads are
+  // pinned in front of the inverse transform (wino_epilogue<.., PIN>) and the lane constants of the patch DMA /
+  // transform are rebuilt per tile so that they are dead across the epilogue: 8 loads in flight, ONE wait after the
+  // first channel group's transform, 243 VGPRs and no spill (was 256 with 3 spills).  NOT yet timed on hardware
+  // (found by reading the ISA after round 3's GPU budget was spent), therefore OFF by default: build the A/B variant
+  // with -DPA_WINO_REFRESH=1 (tools/build_variants.py: "refresh").  The other instantiations do not change.
+  constexpr bool REFRESH = PA_WINO_REFRESH && HAS_R && TR == 2 && TCG == 2;
   int prel[G::NPP];
-  wino_patch_lanes<TR, TCG>(prel, W, CIN, lane, slw, x0_last);
+  if (!REFRESH) wino_patch_lanes<TR, TCG>(prel, W, CIN, lane, slw, x0_last);
   f32x4 acc[16][2];
   int pbase[8];
-  wino_patch_bases<TR, TCG>(pbase, t, g, wr, wc);
+  if (!REFRESH) wino_patch_bases<TR, TCG>(pbase, t, g, wr, wc);
   const float m1 = wino_minus_one();
 #if PA_WINO_STAMP
   unsigned long long st_[STAMP_PH] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -387,6 +406,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
 #endif
   {
     while (q >= 0) {
+      if (REFRESH) {
+        // the lane constants of the patch DMA / transform are rebuilt per tile (an opaque copy of the lane number
+        // keeps the compiler from hoisting them back): they are then dead across the epilogue, which needs the
+        // registers to keep all eight residual vectors in flight
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        wino_patch_lanes<TR, TCG>(prel, W, CIN, lane_v, slw, x0_last);
+        wino_patch_bases<TR, TCG>(pbase, lane_v & 15, lane_v >> 4, wr, wc);
+      }
       const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
       if (tid == 0) ahead = tq_claim_own(tq);
       for (int c0 = 0; c0 < CIN; c0 += WCB) {
@@ -440,8 +468,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
       // (Issuing the NEXT tile's first stage in front of this epilogue, so that the epilogue hides its flight
       // time, was measured 3-8 % SLOWER on every layer shape: profiles/r3_wino_next_tile_prefetch.txt -- the
       // extra DMA issue lands in the phase where the other workgroup's MFMA stream owns the SIMD.)
-      wino_epilogue<HAS_R, false, RPRE>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1, nullptr, nullptr,
-                                        rbuf + 4 * lane);
+      wino_epilogue<HAS_R, false, RPRE, REFRESH && PA_WINO_RPIN>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc,
+                                                                 m1, nullptr, nullptr, rbuf + 4 * lane);
       WINO_STAMP(7);
       WINO_STAMP_FLUSH();
       if (tid == 0) *s_next = tq_resolve(tq, ahead);
