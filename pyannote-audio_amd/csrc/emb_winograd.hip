@@ -61,9 +61,6 @@
 #endif
 // (nt / "streaming" cache-policy bits on the patch DMA, the residual loads or the stores: measured neutral to
 //  10-25 % slower, profiles/r3_wino_cache_policy.txt -- every access keeps the default policy)
-#ifndef PA_WINO_RREG
-#define PA_WINO_RREG 0
-#endif
 #ifndef PA_WINO_RPIN
 #define PA_WINO_RPIN 1
 #endif
@@ -298,7 +295,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
                                               const float* __restrict__ R, float* __restrict__ Y,
                                               int relu, int t, int g, int wr, int wc, float m1,
                                               const int* off_pre = nullptr, f32x4 (*rv_pre)[4] = nullptr,
-                                              const float* rbuf = nullptr, const f32x4* rv1_pre = nullptr) {
+                                              const float* rbuf = nullptr) {
   const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
       Y + (long)q.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -317,9 +314,8 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
     for (int e = 0; e < 4; ++e) {
       const int cg = (PRE0 && HAS_R) ? 1 - cgi : cgi;   // PRE0: the global loads of group 1 go out first
       if (PRE && HAS_R) rv[cg][e] = rv_pre[cg][e];
-      else if (PRE0 && HAS_R && cg == 1 && rv1_pre != nullptr) rv[1][e] = rv1_pre[e];   // (loaded before the last MFMA run)
       else if (PRE0 && HAS_R && cg == 0) {
-        if (e == 0 && rv1_pre == nullptr) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the 4 loads of cg = 1 are newer
+        if (e == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the 4 loads of cg = 1 are newer
         rv[0][e] = *reinterpret_cast<const f32x4*>(rbuf + 256 * e);
       } else
         rv[cg][e] = HAS_R ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off[e] + 64 * cg, 0, 0))
@@ -397,11 +393,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   // first channel group's transform, 243 VGPRs and no spill (was 256 with 3 spills).  NOT yet timed on hardware
   // (found by reading the ISA after round 3's GPU budget was spent), therefore OFF by default: build the A/B variant
   // with -DPA_WINO_REFRESH=1 (tools/build_variants.py: "refresh").  The other instantiations do not change.
-  // (untimed variant, -DPA_WINO_RREG=1) the 8 x 32-pixel residual instantiation: the SECOND channel group's residual
-  // vectors go to registers before the tile's last MFMA run (the first group goes through LDS, RPRE) -- the 14
-  // registers of the lane constants, rebuilt per tile, pay for them
-  constexpr bool RREG = PA_WINO_RREG && RPRE && TR == 4;
-  constexpr bool REFRESH = (PA_WINO_REFRESH && HAS_R && TR == 2 && TCG == 2) || RREG;
+  constexpr bool REFRESH = PA_WINO_REFRESH && HAS_R && TR == 2 && TCG == 2;
   int prel[G::NPP];
   if (!REFRESH) wino_patch_lanes<TR, TCG>(prel, W, CIN, lane, slw, x0_last);
   f32x4 acc[16][2];
@@ -413,7 +405,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   int st_iter = 0;
 #endif
   {
-    f32x4 rv1[4];
     while (q >= 0) {
       if (REFRESH) {
         // the lane constants of the patch DMA / transform are rebuilt per tile (an opaque copy of the lane number
@@ -453,12 +444,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrd, (lds_ptr_t)(rbuf + 256 * e), 16, off_pre[e], 0, 0, 0);
-          if (RREG) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              rv1[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, off_pre[e] + 64, 0, 0));
-            __builtin_amdgcn_sched_barrier(0);
-          }
         }
         if (RTOUCH && c0 + WCB >= CIN) {
           // one pixel (= one 128-B line of this workgroup's 32 output channels) per thread; its own few
@@ -483,9 +468,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
       // (Issuing the NEXT tile's first stage in front of this epilogue, so that the epilogue hides its flight
       // time, was measured 3-8 % SLOWER on every layer shape: profiles/r3_wino_next_tile_prefetch.txt -- the
       // extra DMA issue lands in the phase where the other workgroup's MFMA stream owns the SIMD.)
-      wino_epilogue<HAS_R, false, RPRE, REFRESH && !RREG && PA_WINO_RPIN>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr,
-                                                                          wc, m1, nullptr, nullptr, rbuf + 4 * lane,
-                                                                          RREG ? rv1 : nullptr);
+      wino_epilogue<HAS_R, false, RPRE, REFRESH && PA_WINO_RPIN>(acc, cur, H, W, COUT, shift, R, Y, relu, t, g, wr, wc,
+                                                                 m1, nullptr, nullptr, rbuf + 4 * lane);
       WINO_STAMP(7);
       WINO_STAMP_FLUSH();
       if (tid == 0) *s_next = tq_resolve(tq, ahead);
