@@ -76,9 +76,9 @@ typedef struct pa_seg_weights {
 /* frames per chunk for `num_samples` (SincNet.num_frames, models/blocks/sincnet.py:82-107) */
 int pa_seg_num_frames(int num_samples, int sinc_stride);
 size_t pa_seg_workspace_bytes(const pa_seg_weights* w, int num_chunks, int num_samples);
-/* The same for callers that know the chunk stride: identical to pa_seg_workspace_bytes unless the EXPERIMENTAL
- * shared sinc layer is switched on (environment PA_SEG_SHARED_SINC=1; overlapping chunks whose stride is a
- * multiple of 10 samples), which needs 320 B per span position more.  pa_seg_forward falls back to the per-chunk
+/* The same for callers that know the chunk stride: identical to pa_seg_workspace_bytes unless the
+ * shared sinc layer applies (overlapping chunks whose stride is a multiple of 10 samples; PA_SEG_SHARED_SINC=0
+ * in the environment switches it off), which needs 320 B per span position more.  pa_seg_forward falls back to the per-chunk
  * layer when the workspace it is given is the smaller one. */
 size_t pa_seg_workspace_bytes_strided(const pa_seg_weights* w, int num_chunks, int num_samples,
                                       int64_t chunk_stride);
@@ -96,8 +96,7 @@ int pa_row_stats(const float* x, long row_stride, long total_len, int rows, int 
 int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, int N, int stride,
                      const float* mean, const float* rstd, float gamma, float beta,
                      const float* filt_packed, float* out, void* stream);
-/* EXPERIMENTAL (not yet run on hardware; off unless PA_SEG_SHARED_SINC=1): the sinc layer once per span of
- * overlapping chunks.  pa_sinc_fir_span: S (80, Pc) = raw filter outputs of wav[0, span) (zeros past wav_len),
+/* The sinc layer once per span of overlapping chunks (what pa_seg_forward runs when the chunk stride allows it).  pa_sinc_fir_span: S (80, Pc) = raw filter outputs of wav[0, span) (zeros past wav_len),
  * Pc = (span - 251) / 10 + 1.  pa_sinc_fix_pool: chunk b starts `positions_per_chunk_step` positions after chunk
  * b - 1; per-chunk affine fix-up of the waveform InstanceNorm, magnitude, maxpool3 -> out (B, 80, P) exactly what
  * pa_sinc_fir_pool writes (up to float rounding: 1e-6 of the peak); tap_sums: 80 floats of scratch. */

@@ -64,8 +64,8 @@
 #ifndef PA_WINO_RPIN
 #define PA_WINO_RPIN 1
 #endif
-#ifndef PA_WINO_REFRESH   // 128-channel residual kernel with pinned residual loads: OFF until it has been timed
-#define PA_WINO_REFRESH 0
+#ifndef PA_WINO_REFRESH   // 128-channel residual kernel with pinned residual loads (-DPA_WINO_REFRESH=0: A/B)
+#define PA_WINO_REFRESH 1
 #endif
 #ifndef PA_WINO_RTOUCH
 #define PA_WINO_RTOUCH 1
@@ -390,9 +390,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   // (ISA of round 3's measured build; its twin without residual is 10 % faster per launch).  There the loads are
   // pinned in front of the inverse transform (wino_epilogue<.., PIN>) and the lane constants of the patch DMA /
   // transform are rebuilt per tile so that they are dead across the epilogue: 8 loads in flight, ONE wait after the
-  // first channel group's transform, 243 VGPRs and no spill (was 256 with 3 spills).  NOT yet timed on hardware
-  // (found by reading the ISA after round 3's GPU budget was spent), therefore OFF by default: build the A/B variant
-  // with -DPA_WINO_REFRESH=1 (tools/build_variants.py: "refresh").  The other instantiations do not change.
+  // first channel group's transform, 243 VGPRs and no spill (was 256 with 3 spills).  Measured in round 4 (B = 512,
+  // 20x250x128 + residual, two runs on one box): 3.169 -> 3.136 ms and 3.177 -> 3.127 ms (-1.3 %), results identical
+  // (tests/test_emb_gpu.py); tools/build_variants.py "norefresh" builds the old form.  The other instantiations do
+  // not change.
   constexpr bool REFRESH = PA_WINO_REFRESH && HAS_R && TR == 2 && TCG == 2;
   int prel[G::NPP];
   if (!REFRESH) wino_patch_lanes<TR, TCG>(prel, W, CIN, lane, slw, x0_last);

@@ -18,16 +18,18 @@ struct SegPlan {
   // offsets in floats
   size_t wav_mean, wav_rstd, s1, st1m, st1r, s2, st2m, st2r, s3, st3m, st3r, x0, xproj, h0, h1, l0, l1,
       total;
-  // the sinc layer once per span of overlapping chunks (EXPERIMENTAL, PA_SEG_SHARED_SINC=1): raw filter outputs
-  // of the whole span + the tap sums
+  // the sinc layer once per span of overlapping chunks (default; PA_SEG_SHARED_SINC=0 selects the per-chunk layer
+  // for an A/B): raw filter outputs of the whole span + the tap sums
   long span, span_pos;
   size_t span_s, tap_sums;
 };
 
-// EXPERIMENTAL, off by default: see seg_frontend.hip (k_sinc_fix_pool)
+// see seg_frontend.hip (k_sinc_fix_pool).  Measured on MI355X (round 4, one audio-hour = 3 591 chunks): k_sinc_fir_pool
+// 21.2 ms -> k_sinc_fir_span 2.6 ms + k_sinc_fix_pool 3.2 ms, pipeline step 914.9 -> 903.7 ms; parity test
+// tests/test_seg_gpu.py::test_shared_sinc_layer_matches_the_per_chunk_layer.
 inline bool shared_sinc_wanted(const pa_seg_weights* w, int B, int N, int64_t chunk_stride) {
   const char* e = getenv("PA_SEG_SHARED_SINC");
-  return e != nullptr && atoi(e) == 1 && w->sinc_stride == 10 && B >= 2 && chunk_stride > 0 && chunk_stride < N &&
+  return (e == nullptr || atoi(e) != 0) && w->sinc_stride == 10 && B >= 2 && chunk_stride > 0 && chunk_stride < N &&
          chunk_stride % 10 == 0 && (int64_t)(B - 1) * chunk_stride + N <= 0x7fffffffLL;
 }
 

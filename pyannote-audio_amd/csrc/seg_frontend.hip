@@ -138,9 +138,10 @@ __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
 }
 
 // ---------------------------------------------------------------------------------------------
-// The sinc layer once per SPAN of overlapping chunks (EXPERIMENTAL: written after round 3's GPU budget was spent,
-// numerics cleared on the CPU with tools/probes/shared_sinc_numerics.py, NOT yet run on hardware; off unless
-// PA_SEG_SHARED_SINC=1, pa_seg_forward).  Chunks of the sliding window start at multiples of Q = chunk_stride /
+// The sinc layer once per SPAN of overlapping chunks (the default of pa_seg_forward for overlapping chunks whose
+// stride is a multiple of 10 samples; PA_SEG_SHARED_SINC=0 selects the per-chunk kernel for an A/B.  Numerics:
+// tools/probes/shared_sinc_numerics.py on the CPU, tests/test_seg_gpu.py::test_shared_sinc_layer_* on MI355X;
+// measured per audio-hour: 21.2 ms -> 2.6 + 3.2 ms).  Chunks of the sliding window start at multiples of Q = chunk_stride /
 // 10 convolution positions and the waveform InstanceNorm is affine, so with S = sinc(raw span), S1[f] = sum of
 // the taps of filter f and g = rstd * gamma:
 //     sinc((x - mu) g + beta)[f][q] = g (S[f][c Q + q] - mu S1[f]) + beta S1[f]

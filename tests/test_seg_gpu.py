@@ -178,12 +178,9 @@ def test_seg_forward_end_to_end(seg, gpu_device, B, N, stride):
     assert north_star_ratio(f"seg_forward_contract_N{N}", out, ref[:2]) <= 1.0
 
 
-@pytest.mark.skipif(os.environ.get("PA_TEST_SHARED_SINC") != "1",
-                    reason="EXPERIMENTAL path, not yet run on hardware (written after round 3's GPU budget was "
-                           "spent): PA_TEST_SHARED_SINC=1 python -m pytest tests/test_seg_gpu.py -m gpu -k shared_sinc")
 def test_shared_sinc_layer_matches_the_per_chunk_layer(seg, gpu_device):
     """The sinc layer computed ONCE for a span of overlapping chunks + per-chunk affine fix-up (pa_sinc_fir_span,
-    pa_sinc_fix_pool; pa_seg_forward with PA_SEG_SHARED_SINC=1) against the per-chunk layer: the pooled magnitudes
+    pa_sinc_fix_pool; the default of pa_seg_forward) against the per-chunk layer (PA_SEG_SHARED_SINC=0): the pooled magnitudes
     within the element-wise tolerance of the oracle, and the whole forward within it too (the CPU study
     tools/probes/shared_sinc_numerics.py: log-probabilities move by 2.5e-5, no hard decision changes)."""
     import pyannote_audio_amd.ffi as ffi

@@ -8,7 +8,7 @@ from pyannote_audio_amd import _build
 
 VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or None for the work tree)
     "stamp": ("emb_winograd.hip", "-DPA_WINO_STAMP=1", None),
-    "refresh": ("emb_winograd.hip", "-DPA_WINO_REFRESH=1", None),   # 128-channel residual kernel: residual loads pinned (untimed)
+    "norefresh": ("emb_winograd.hip", "-DPA_WINO_REFRESH=0", None),   # 128-channel residual kernel without the pinned residual loads
     "nortouch": ("emb_winograd.hip", "-DPA_WINO_RTOUCH=0", None),   # without the residual line touch
     "norpre": ("emb_winograd.hip", "-DPA_WINO_RPRE=0", None),   # without the residual prefetch through LDS
 }
