@@ -176,7 +176,11 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid(double* __restrict__ 
                                                             int* __restrict__ g_kbi,
                                                             int* __restrict__ g_ibk,
                                                             int* __restrict__ g_nb,
-                                                            long long* __restrict__ stats) {
+                                                            long long* __restrict__ stats,
+                                                            const int* __restrict__ gate) {
+  // `gate`: status word of the fast path (linkage_fast.hip) that ran in front of this launch on the same stream;
+  // 0 = the dendrogram is already complete
+  if (gate != nullptr && *gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ MinPair red[LK_W];
   __shared__ int sh_x, sh_y, sh_ok, sh_nx, sh_ny, sh_npend;
@@ -488,7 +492,9 @@ __global__ __launch_bounds__(LK_T) void k_linkage_centroid_mw(double* __restrict
                                                                double* __restrict__ mind,
                                                                unsigned int* __restrict__ cand,
                                                                LkShared* __restrict__ sh, int G,
-                                                               long long* __restrict__ stats) {
+                                                               long long* __restrict__ stats,
+                                                               const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;   // the fast path (linkage_fast.hip) completed the dendrogram
   if ((blockIdx.x & 7) != 0) return;     // only the workgroups of one XCD take part
   const int wg = blockIdx.x >> 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -759,32 +765,40 @@ constexpr size_t LK_LDS_MAX = 160 * 1024 - 7680;  // dynamic LDS budget (static 
 
 inline size_t lk_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// linkage_fast.hip: the heap-free merge that runs first; the kernels of this file are its gated fallback
+bool lf_wanted(int n);
+size_t lf_workspace_bytes(int n);
+int lf_launch(const double* cond, int n, double* Z, void* workspace, long long* stats, int** gate_out,
+              hipStream_t st);
+
+// size, cluster_id, neighbour, kbi, ibk (int) + heap values, min_dist mirror (double) + candidate bitmap + the
+// multi-workgroup mailbox
+inline size_t lk_core_bytes(int n) {
+  const size_t ni = lk_align(sizeof(int) * (size_t)n), nd = lk_align(sizeof(double) * (size_t)n);
+  return 5 * ni + 2 * nd + lk_align(4 * (size_t)((n + 31) / 32) + 16) + lk_align(sizeof(LkShared));
+}
+
 }  // namespace pa
 
 extern "C" {
 
+// layout: [heap kernel state][fast path: square matrix + row state][16 int64 counters: 8 heap kernel, 8 fast path]
 size_t pa_linkage_workspace_bytes(int n) {
   if (n < 2) return 0;
-  const size_t ni = pa::lk_align(sizeof(int) * (size_t)n), nd = pa::lk_align(sizeof(double) * (size_t)n);
-  // size, cluster_id, neighbour, kbi, ibk (int) + heap values, min_dist mirror (double) + candidate bitmap +
-  // the multi-workgroup mailbox + 8 counters
-  return 5 * ni + 2 * nd + pa::lk_align(4 * (size_t)((n + 31) / 32) + 16) + pa::lk_align(sizeof(pa::LkShared)) + 64;
+  return pa::lk_core_bytes(n) + pa::lf_workspace_bytes(n) + 128;
 }
 
-// number of workgroups of the merge kernel: PA_LINKAGE_WGS overrides (1 = the single-workgroup kernel)
+// number of workgroups of the heap kernel.  ONE unless PA_LINKAGE_WGS asks for more: the multi-workgroup form
+// synchronises with a hand-rolled spin barrier between workgroups that are launched non-cooperatively and each pin a
+// whole CU's LDS; it is only safe when the caller owns the GPU (nothing else resident on XCD 0), which a library
+// cannot know.  Since round 4 the heap kernels are the FALLBACK (exact ties) behind linkage_fast.hip, so the
+// default never needs it; the opt-in stays for experiments (tools/time_linkage.py).
 static int lk_num_workgroups(int n, int alone) {
+  (void)n;
+  (void)alone;
   const char* e = getenv("PA_LINKAGE_WGS");
   if (e != nullptr && atoi(e) >= 1) return atoi(e) > 32 ? 32 : atoi(e);
-  // `alone`: the caller knows that no front end runs beside this merge (a single file, the last file of a batch)
-  if (alone && n >= 6000 && n < 12000) return 8;
-  // measured: the split pass wins when the O(N) pass dominates the merge.  On the joint clustering of REAL
-  // embeddings (profiles/r3_joint_scale.txt) 16 workgroups take 0.92 -> 0.78 s at N = 14 k (8 workgroups: 0.72 s),
-  // 3.59 -> 2.02 s at 29 k, 14.2 -> 6.7 s at 57 k; on the 4-blob synthetic set of tools/time_linkage.py, which needs
-  // 10x as many heap updates per merge, only the largest size gains (profiles/r3_linkage_multi_workgroup.txt).
-  // One audio-hour (N = 7 176, profiles/r3_linkage_even_split.txt): 8 workgroups 183 ms vs 195 ms alone, but beside
-  // the next file's embedding stage they cost that stage 5 ms -- one workgroup stays the default below 12 k.
-  // <= 16 workgroups: two concurrent merges (two processes on one GPU) still fit one XCD.
-  return n >= 20000 ? 16 : (n >= 12000 ? 8 : 1);
+  return 1;
 }
 
 // D: condensed distance matrix (n*(n-1)/2 doubles), OVERWRITTEN.  Z: (n-1, 4) doubles, SciPy layout.
@@ -812,10 +826,17 @@ int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, siz
   double* mind = (double*)(w + 5 * ni + nd);
   unsigned int* cand = (unsigned int*)(w + 5 * ni + 2 * nd);
   pa::LkShared* shared = (pa::LkShared*)(w + 5 * ni + 2 * nd + pa::lk_align(cand_bytes));
-  long long* stats = (long long*)(w + pa_linkage_workspace_bytes(n) - 64);
+  long long* stats = (long long*)(w + pa_linkage_workspace_bytes(n) - 128);
   hipStream_t st = (hipStream_t)stream;
   // the merge loop is O(N^2) memory traffic in total; algorithmic bytes ~ 3 rows of 8*N per merge
   pa::ProfScope prof("k_linkage_centroid", stream, 9.0 * n * (double)n, 24.0 * n * (double)n);
+  if (hipMemsetAsync(stats, 0, 128, st) != hipSuccess) return 1;
+  // ---- the heap-free merge first (linkage_fast.hip); its status word gates the exact heap replay below
+  int* gate = nullptr;
+  if (pa::lf_wanted(n)) {
+    if (pa::lf_launch(D, n, Z, w + pa::lk_core_bytes(n), stats + 8, &gate, st) != 0) return 1;
+    PA_CHECK_LAUNCH("pa_linkage_centroid_f64 (fast path)");
+  }
   const int G = lk_num_workgroups(n, alone);
   if (G > 1) {
     if (hipMemsetAsync(shared, 0, sizeof(pa::LkShared), st) != hipSuccess) return 1;
@@ -824,10 +845,10 @@ int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, siz
       (void)hipFuncSetAttribute((const void*)pa::k_linkage_centroid_mw<unsigned short, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa::LK_LDS_MAX);
       hipLaunchKernelGGL((pa::k_linkage_centroid_mw<unsigned short, true>), dim3(8 * G), dim3(pa::LK_T), lds_heap,
-                         st, D, n, Z, size, cid, hv, kbi, ibk, nb, mind, cand, shared, G, stats);
+                         st, D, n, Z, size, cid, hv, kbi, ibk, nb, mind, cand, shared, G, stats, gate);
     } else {
       hipLaunchKernelGGL((pa::k_linkage_centroid_mw<int, false>), dim3(8 * G), dim3(pa::LK_T), 0, st, D, n, Z,
-                         size, cid, hv, kbi, ibk, nb, mind, cand, shared, G, stats);
+                         size, cid, hv, kbi, ibk, nb, mind, cand, shared, G, stats, gate);
     }
     PA_CHECK_LAUNCH("pa_linkage_centroid_f64");
     return 0;
@@ -838,10 +859,10 @@ int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, siz
     (void)hipFuncSetAttribute((const void*)pa::k_linkage_centroid<unsigned short, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa::LK_LDS_MAX);
     hipLaunchKernelGGL((pa::k_linkage_centroid<unsigned short, true>), dim3(1), dim3(pa::LK_T), lds16, st,
-                       D, n, Z, size, cid, hv, kbi, ibk, nb, stats);
+                       D, n, Z, size, cid, hv, kbi, ibk, nb, stats, gate);
   } else {
     hipLaunchKernelGGL((pa::k_linkage_centroid<int, false>), dim3(1), dim3(pa::LK_T), cand_bytes, st, D, n,
-                       Z, size, cid, hv, kbi, ibk, nb, stats);
+                       Z, size, cid, hv, kbi, ibk, nb, stats, gate);
   }
   PA_CHECK_LAUNCH("pa_linkage_centroid_f64");
   return 0;

@@ -65,8 +65,10 @@ def device_to_ourselves():
 @ffi.on_device(lambda X, device: device)
 def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     """scipy.cluster.hierarchy.linkage(X, method="centroid", metric="euclidean") entirely on the GPU:
-    float64 pdist (`pa_pdist_f64`) feeds the persistent merge kernel (`pa_linkage_centroid_f64`) without
-    leaving HBM; only the (n-1, 4) dendrogram comes back.  Bit-identical to SciPy (csrc/linkage.hip)."""
+    float64 pdist (`pa_pdist_f64`) feeds the persistent merge kernels (`pa_linkage_centroid_f64`: the heap-free
+    merge of csrc/linkage_fast.hip, then -- only if two rows ever tied for the smallest lower bound -- the exact
+    heap replay of csrc/linkage.hip) without leaving HBM; only the (n-1, 4) dendrogram comes back.  Bit-identical
+    to SciPy."""
     n = X.shape[0]
     ffi.require_gpu()
     lib = ffi.load()
@@ -79,7 +81,10 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
                                              1 if getattr(_hint, "alone", False) else 0, ffi.stream()),
               "pa_linkage_centroid_f64")
     global last_linkage_stats
-    last_linkage_stats = ws[-64:].view(torch.int64).cpu().numpy()   # development counters
+    # development counters: [0:8] heap kernel (csrc/linkage.hip; all zero when the heap-free merge completed the
+    # dendrogram), [8:16] heap-free merge (csrc/linkage_fast.hip): status (0 = complete, 1 = tie -> heap, 2 =
+    # degenerate input -> heap), lower-bound repairs, cycles in pop / rest, n
+    last_linkage_stats = ws[-128:].view(torch.int64).cpu().numpy()
     return Z.cpu().numpy()
 
 

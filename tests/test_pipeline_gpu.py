@@ -127,10 +127,10 @@ def test_linkage_centroid_bit_exact_vs_scipy(gpu_device, n, d, dup, seed):
 
 @pytest.mark.parametrize("n,workgroups", [(12300, None), (3000, 4), (12300, 1)])
 def test_linkage_multi_workgroup_vs_scipy(gpu_device, n, workgroups, monkeypatch):
-    """the multi-workgroup merge (k_linkage_centroid_mw: O(N) pass split over the workgroups of one XCD, heap
-    replay on workgroup 0, sc1 accesses instead of fences) in its LDS-heap range -- N = 12 300 picks 8
-    workgroups by itself; a forced 4-workgroup run on a small problem; the single-workgroup kernel at the same
-    size -- bit-identical to SciPy, exact ties included."""
+    """the heap kernels of csrc/linkage.hip on data WITH exact ties (duplicated rows: the heap-free merge gives up at
+    its first pop and the gated heap kernel recomputes the dendrogram): the default at N = 12 300 (one workgroup,
+    heap in global memory), a forced 4-workgroup run (k_linkage_centroid_mw, opt-in through PA_LINKAGE_WGS) on a
+    small problem, a forced single workgroup -- bit-identical to SciPy."""
     from scipy.cluster.hierarchy import linkage
     from scipy.spatial.distance import pdist
     from pyannote_audio_amd import distance
@@ -145,6 +145,45 @@ def test_linkage_multi_workgroup_vs_scipy(gpu_device, n, workgroups, monkeypatch
     got = distance.linkage_centroid(X, gpu_device)
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
+    st = distance.last_linkage_stats
+    assert st[8] == 1 and st[7] == n, "expected: heap-free merge gave up on a tie, heap kernel ran"
+
+
+@pytest.mark.parametrize("n,d", [(3, 8), (700, 16), (4000, 64), (7176, 256), (12300, 32)])
+def test_linkage_heap_free_merge_vs_scipy(gpu_device, n, d):
+    """csrc/linkage_fast.hip (arg-min over the lower bounds instead of SciPy's heap, EXACT bit per row, square
+    matrix) on tie-free data: it completes the dendrogram by itself (status 0, the heap kernel returns at its gate)
+    and the result is bit-identical to SciPy.  N = 7 176 is one audio-hour (row state in LDS), 12 300 has the row
+    state in global memory."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+    from pyannote_audio_amd import distance
+    rng = np.random.default_rng(n)
+    centers = rng.standard_normal((4, d))
+    X = (centers[rng.integers(0, 4, n)] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    want = linkage(pdist(X), method="centroid")
+    got = distance.linkage_centroid(X, gpu_device)
+    st = distance.last_linkage_stats
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]} (status {st[8]})"
+    assert st[8] == 0 and st[7] == 0, f"heap-free merge did not complete: status {st[8]}, heap kernel n {st[7]}"
+
+
+def test_linkage_late_tie_falls_back_to_the_heap(gpu_device):
+    """mirrored pairs (u, v), (-u, -v) have the same float64 distance: they meet as the two smallest lower bounds at
+    merge 72 (tests/linkage_model.py), where the heap-free merge gives up in the MIDDLE of the dendrogram and the
+    heap kernel recomputes it from the untouched condensed matrix: SciPy's result."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+    from pyannote_audio_amd import distance
+    from linkage_model import late_tie_points
+    X = late_tie_points()
+    want = linkage(pdist(X), method="centroid")
+    got = distance.linkage_centroid(X, gpu_device)
+    assert np.array_equal(got, want)
+    st = distance.last_linkage_stats
+    assert st[8] == 1 and st[7] == len(X)
 
 
 def test_non_powerset_pipeline_matches_oracle(synthetic_models, gpu_device, tmp_path):

@@ -21,10 +21,16 @@ def run(X, G):
     t = time.perf_counter()
     Z = distance.linkage_centroid(X.copy(), dev)
     dt = time.perf_counter() - t
+    return Z, dt, describe(len(X))
+
+
+def describe(n):
     st = distance.last_linkage_stats
-    n = len(X)
-    return Z, dt, (f"retries/merge {st[0] / n:.2f} heap-updates/merge {st[1] / n:.2f} overflows {st[2]} "
-                   f"cycles(find, wait, pass, replay)/merge {[int(c / n) for c in st[3:7]]}")
+    fast = (f"fast path: status {st[8]} repairs/merge {st[9] / n:.2f} cycles(pop, rest)/merge "
+            f"{[int(c / n) for c in st[10:12]]}") if st[12] else "fast path: off"
+    heap = (f"heap kernel: retries/merge {st[0] / n:.2f} heap-updates/merge {st[1] / n:.2f} overflows {st[2]} "
+            f"cycles(find, wait, pass, replay)/merge {[int(c / n) for c in st[3:7]]}") if st[7] else "heap kernel: skipped"
+    return fast + " | " + heap
 
 
 def sweep(name, X, scipy_check):
@@ -33,8 +39,21 @@ def sweep(name, X, scipy_check):
         t = time.perf_counter()
         ref = linkage(pdist(X), "centroid")
         print(f"{name}: scipy pdist + linkage {1e3 * (time.perf_counter() - t):.0f} ms", flush=True)
-    for G in [int(g) for g in os.environ.get("LK_GS", "1,2,4,8,16").split(",")]:
-        Z, dt, info = run(X, G)
+    for G in [int(g) for g in os.environ.get("LK_GS", "0,1,8,16").split(",")]:
+        # G = 0: the default (heap-free merge first); G >= 1: PA_LINKAGE_FAST=0, the heap kernel with G workgroups
+        if G == 0:
+            os.environ.pop("PA_LINKAGE_FAST", None)
+            os.environ.pop("PA_LINKAGE_WGS", None)
+            distance.linkage_centroid(X[:64].copy(), dev)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            Z = distance.linkage_centroid(X.copy(), dev)
+            dt = time.perf_counter() - t
+            info = describe(len(X))
+        else:
+            os.environ["PA_LINKAGE_FAST"] = "0"
+            Z, dt, info = run(X, G)
+            os.environ.pop("PA_LINKAGE_FAST", None)
         if ref is None:
             ref = Z
         print(f"{name}: n={len(X)} workgroups={G:2d} {1e3 * dt:8.1f} ms  identical={np.array_equal(Z, ref)}  {info}",
@@ -50,7 +69,8 @@ for n in [int(a) for a in sys.argv[1:]] or [7000, 20000, 57000]:
     c = rng.standard_normal((4, 256))
     X = (c[rng.integers(0, 4, n)] + 0.6 * rng.standard_normal((n, 256))).astype(np.float32)
     X /= np.linalg.norm(X, axis=1, keepdims=True)
-    if n >= 20000:           # exact ties: duplicated rows
-        X[n // 2: n // 2 + 500] = X[:500]
     sweep("synthetic", X, n <= 7000)
+    if n >= 20000:           # exact ties (duplicated rows): the heap-free merge gives up at its first pop
+        X[n // 2: n // 2 + 500] = X[:500]
+        sweep("synthetic + 500 duplicated rows", X, False)
 os.environ.pop("PA_LINKAGE_WGS", None)
