@@ -83,7 +83,8 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     global last_linkage_stats
     # development counters: [0:8] heap kernel (csrc/linkage.hip; all zero when the heap-free merge completed the
     # dendrogram), [8:16] heap-free merge (csrc/linkage_fast.hip): status (0 = complete, 1 = tie -> heap, 2 =
-    # degenerate input -> heap), lower-bound repairs, cycles in pop / rest, n
+    # degenerate input -> heap, 3 = a workgroup
+    # never showed up -> heap), lower-bound repairs, cycles in pop / pass, n, workgroups, re-publishes, merges done
     last_linkage_stats = ws[-128:].view(torch.int64).cpu().numpy()
     return Z.cpu().numpy()
 

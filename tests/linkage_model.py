@@ -1,54 +1,126 @@
 """Python model of the heap-free centroid-linkage merge of csrc/linkage_fast.hip (test infrastructure): the same
-state (lower bound, neighbour candidate, EXACT bit, size, id per row), the same update rules, the same give-up rule
-(a pop whose smallest bound is attained twice -> None, the launcher then runs the heap kernel).  The CPU suite checks
-the MODEL against scipy.cluster.hierarchy.linkage(., "centroid") (tests/test_linkage_fast_model.py); the GPU suite
-checks the KERNEL against SciPy (tests/test_pipeline_gpu.py)."""
+per-row state (lower bound, neighbour candidate, EXACT bit, size, id), the same update rules, the same candidate
+exchange between workgroups (every workgroup publishes its two smallest rows; a repaired row invalidates its
+workgroup's second candidate; the freshly merged row travels as a pseudo candidate), the same give-up rule (a pop
+whose smallest bound is attained twice -> None, the launcher then runs the heap kernel of csrc/linkage.hip).
+The CPU suite checks the MODEL against scipy.cluster.hierarchy.linkage(., "centroid")
+(tests/test_linkage_fast_model.py); the GPU suite checks the KERNEL against SciPy (tests/test_pipeline_gpu.py)."""
 import numpy as np
 from scipy.spatial.distance import pdist, squareform
 
+INF = np.inf
 
-def fast_linkage_model(X):
-    """-> (Z or None, merge index of the give-up or number of lower-bound repairs)"""
+
+def fast_linkage_model(X, G=1, CH=1024, stats=None):
+    """-> (Z or None, merge index of the give-up or number of lower-bound repairs).  G workgroups own the rows in
+    interleaved chunks of CH rows (row z belongs to workgroup (z // CH) % G)."""
     n = len(X)
     S = squareform(pdist(X))
-    size = np.ones(n, int); cid = np.arange(n)
-    mind = np.full(n, np.inf); nb = np.full(n, -1); ex = np.zeros(n, bool)
-    for x in range(n-1):
-        row = S[x, x+1:]
-        j = int(np.argmin(row)); mind[x] = row[j]; nb[x] = x+1+j; ex[x] = True
-    Z = np.zeros((n-1, 4)); reps = 0
-    for k in range(n-1):
-        while True:
-            m = mind.min()
-            idx = np.nonzero(mind == m)[0]
-            if len(idx) > 1 or not np.isfinite(m):
+    size = np.ones(n, int)
+    cid = np.arange(n)
+    mind = np.full(n, INF)
+    nb = np.full(n, -1)
+    ex = np.zeros(n, bool)
+    for x in range(n - 1):
+        row = S[x, x + 1:]
+        j = int(np.argmin(row))
+        mind[x] = row[j]
+        nb[x] = x + 1 + j
+        ex[x] = True
+    owner = lambda z: (z // CH) % G
+    rows_of = [[z for z in range(n) if owner(z) == g] for g in range(G)]
+    Z = np.zeros((n - 1, 4))
+    reps = republishes = 0
+
+    def local_top2(g, exclude):
+        c = sorted((mind[z], z) for z in rows_of[g] if z != exclude and mind[z] < INF)
+        return (c + [None, None])[:2]
+
+    pend_y = -1
+    passbest = None
+    k = 0
+    mode = "main"
+    cand = [[None, None] for _ in range(G)]
+    inval = [False] * G
+    rep = [-1] * G
+    yentry = None
+    tries = 0
+    while k < n - 1:
+        if mode in ("main", "republish"):
+            for g in range(G):
+                cand[g] = local_top2(g, pend_y if mode == "main" else -1)
+                inval[g] = False
+            yentry = None
+            if mode == "main" and pend_y >= 0:
+                d, i = passbest
+                if pend_y < n - 1:
+                    if i < 0:
+                        return None, k
+                    mind[pend_y], nb[pend_y], ex[pend_y] = d, i, True
+                    yentry = (d, pend_y)
+                pend_y = -1
+            if mode == "republish":
+                republishes += 1
+        # ---- pop
+        C = [(c[0], c[1], g) for g in range(G) for c in cand[g] if c is not None]
+        if yentry is not None:
+            C.append((yentry[0], yentry[1], -1))
+        C.sort()
+        if not C:
+            return None, k
+        if len(C) > 1 and C[1][0] == C[0][0]:
+            return None, k                      # tie at the pop: take the heap
+        dist, x, g = C[0]
+        if g >= 0 and inval[g] and x != rep[g]:
+            mode = "republish"
+            continue
+        y = nb[x]
+        if not (ex[x] and y >= 0):
+            tries += 1
+            if tries > n - k:
                 return None, k
-            x = int(idx[0]); dist = m; y = nb[x]
-            if ex[x] and y >= 0: break
-            best, bi = np.inf, -1
-            for i in range(x+1, n):
-                if size[i] and S[x, i] < best: best, bi = S[x, i], i
-            nb[x] = bi; mind[x] = best; ex[x] = bi >= 0; reps += 1
+            best, bi = INF, -1
+            for i in range(x + 1, n):
+                if size[i] and S[x, i] < best:
+                    best, bi = S[x, i], i
+            nb[x], mind[x], ex[x] = bi, best, bi >= 0
+            reps += 1
+            which = 0 if (cand[g][0] is not None and cand[g][0][1] == x) else 1
+            cand[g][which] = (best, x) if bi >= 0 else None
+            inval[g], rep[g] = True, x
+            mode = "pop"
+            continue
+        tries = 0
+        # ---- merge
         nx, ny = size[x], size[y]
         a, b = sorted((cid[x], cid[y]))
-        Z[k] = (a, b, dist, nx+ny)
-        best, bi = np.inf, -1
+        Z[k] = (a, b, dist, nx + ny)
+        best, bi = INF, -1
         for z in range(n):
-            if z == x or z == y or size[z] == 0: continue
+            if z == x or z == y or size[z] == 0:
+                continue
             dx, dy = S[x, z], S[y, z]
-            nd = np.sqrt((((nx*dx*dx) + (ny*dy*dy)) - ((nx*ny)*dist*dist)/(nx+ny)) / (nx+ny))
-            S[y, z] = nd; S[z, y] = nd
+            nd = np.sqrt((((nx * dx * dx) + (ny * dy * dy)) - ((nx * ny) * dist * dist) / (nx + ny)) / (nx + ny))
+            S[y, z] = nd
+            S[z, y] = nd
             if z < y:
                 c = nb[z]
                 if nd < mind[z]:
-                    mind[z] = nd; nb[z] = y; ex[z] = True
+                    mind[z], nb[z], ex[z] = nd, y, True
                 elif c == x or c == y:
-                    nb[z] = y; ex[z] = mind[z] == nd
+                    nb[z], ex[z] = y, mind[z] == nd
             elif nd < best:
                 best, bi = nd, z
-        mind[x] = np.inf; size[x] = 0; size[y] = nx+ny; cid[y] = n+k
-        if y < n-1 and bi >= 0:
-            nb[y] = bi; mind[y] = best; ex[y] = True
+        mind[x] = INF
+        size[x] = 0
+        size[y] = nx + ny
+        cid[y] = n + k
+        mind[y] = INF          # (the row's new bound arrives with the next exchange)
+        pend_y, passbest = y, (best, bi)
+        k += 1
+        mode = "main"
+    if stats is not None:
+        stats.update(repairs=reps, republishes=republishes)
     return Z, reps
 
 

@@ -17,10 +17,12 @@ def _points(n, d, seed):
     return X.astype(np.float64)
 
 
-@pytest.mark.parametrize("n,d,seed", [(3, 4, 0), (4, 4, 1), (10, 3, 2), (60, 8, 3), (150, 16, 4), (300, 4, 5)])
-def test_model_is_scipy_when_no_pop_ties(n, d, seed):
+@pytest.mark.parametrize("n,d,seed,G,CH", [(3, 4, 0, 1, 1024), (4, 4, 1, 2, 1), (10, 3, 2, 2, 2), (60, 8, 3, 3, 4),
+                                            (150, 16, 4, 1, 1024), (300, 4, 5, 16, 4), (200, 8, 6, 5, 3)])
+def test_model_is_scipy_when_no_pop_ties(n, d, seed, G, CH):
+    """G workgroups owning interleaved chunks of CH rows, candidate exchange with two candidates per workgroup"""
     X = _points(n, d, seed)
-    Z, repairs = fast_linkage_model(X)
+    Z, repairs = fast_linkage_model(X, G, CH)
     assert Z is not None, "unexpected tie in random data"
     assert np.array_equal(Z, linkage(pdist(X), "centroid"))
     assert repairs > 0 or n < 10      # the lower-bound repair path is exercised
@@ -37,5 +39,6 @@ def test_model_gives_up_on_duplicated_rows():
 def test_model_gives_up_on_a_late_tie():
     """mirrored pairs (u, v) and (-u, -v): the same float64 distance, tied only once both are the smallest bounds"""
     from linkage_model import late_tie_points
-    Z, at = fast_linkage_model(late_tie_points().astype(np.float64))
-    assert Z is None and at == 72
+    for G, CH in ((1, 1024), (4, 16)):
+        Z, at = fast_linkage_model(late_tie_points().astype(np.float64), G, CH)
+        assert Z is None and at == 72

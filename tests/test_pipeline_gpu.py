@@ -149,15 +149,18 @@ def test_linkage_multi_workgroup_vs_scipy(gpu_device, n, workgroups, monkeypatch
     assert st[8] == 1 and st[7] == n, "expected: heap-free merge gave up on a tie, heap kernel ran"
 
 
-@pytest.mark.parametrize("n,d", [(3, 8), (700, 16), (4000, 64), (7176, 256), (12300, 32)])
-def test_linkage_heap_free_merge_vs_scipy(gpu_device, n, d):
+@pytest.mark.parametrize("n,d,wgs", [(3, 8, None), (700, 16, None), (4000, 64, None), (7176, 256, None),
+                                     (12300, 32, None), (700, 16, 3), (4000, 64, 8), (7176, 256, 16), (12300, 32, 5)])
+def test_linkage_heap_free_merge_vs_scipy(gpu_device, n, d, wgs, monkeypatch):
     """csrc/linkage_fast.hip (arg-min over the lower bounds instead of SciPy's heap, EXACT bit per row, square
-    matrix) on tie-free data: it completes the dendrogram by itself (status 0, the heap kernel returns at its gate)
-    and the result is bit-identical to SciPy.  N = 7 176 is one audio-hour (row state in LDS), 12 300 has the row
-    state in global memory."""
+    matrix, candidate exchange between workgroups) on tie-free data: it completes the dendrogram by itself (status
+    0, the heap kernel returns at its gate) and the result is bit-identical to SciPy.  N = 7 176 is one audio-hour
+    (one workgroup by default), 12 300 takes 16 workgroups by default; `wgs` forces the multi-workgroup form."""
     from scipy.cluster.hierarchy import linkage
     from scipy.spatial.distance import pdist
     from pyannote_audio_amd import distance
+    if wgs is not None:
+        monkeypatch.setenv("PA_LINKAGE_FAST_WGS", str(wgs))
     rng = np.random.default_rng(n)
     centers = rng.standard_normal((4, d))
     X = (centers[rng.integers(0, 4, n)] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
@@ -168,9 +171,11 @@ def test_linkage_heap_free_merge_vs_scipy(gpu_device, n, d):
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]} (status {st[8]})"
     assert st[8] == 0 and st[7] == 0, f"heap-free merge did not complete: status {st[8]}, heap kernel n {st[7]}"
+    assert st[13] == (wgs if wgs is not None else (1 if n <= 10240 else 16))
 
 
-def test_linkage_late_tie_falls_back_to_the_heap(gpu_device):
+@pytest.mark.parametrize("wgs", [None, 4])
+def test_linkage_late_tie_falls_back_to_the_heap(gpu_device, wgs, monkeypatch):
     """mirrored pairs (u, v), (-u, -v) have the same float64 distance: they meet as the two smallest lower bounds at
     merge 72 (tests/linkage_model.py), where the heap-free merge gives up in the MIDDLE of the dendrogram and the
     heap kernel recomputes it from the untouched condensed matrix: SciPy's result."""
@@ -178,12 +183,14 @@ def test_linkage_late_tie_falls_back_to_the_heap(gpu_device):
     from scipy.spatial.distance import pdist
     from pyannote_audio_amd import distance
     from linkage_model import late_tie_points
+    if wgs is not None:
+        monkeypatch.setenv("PA_LINKAGE_FAST_WGS", str(wgs))
     X = late_tie_points()
     want = linkage(pdist(X), method="centroid")
     got = distance.linkage_centroid(X, gpu_device)
     assert np.array_equal(got, want)
     st = distance.last_linkage_stats
-    assert st[8] == 1 and st[7] == len(X)
+    assert st[8] == 1 and st[15] == 72 and st[7] == len(X)   # gave up at merge 72, like the model; the heap ran
 
 
 def test_non_powerset_pipeline_matches_oracle(synthetic_models, gpu_device, tmp_path):

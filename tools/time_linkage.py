@@ -26,8 +26,8 @@ def run(X, G):
 
 def describe(n):
     st = distance.last_linkage_stats
-    fast = (f"fast path: status {st[8]} repairs/merge {st[9] / n:.2f} cycles(pop, rest)/merge "
-            f"{[int(c / n) for c in st[10:12]]}") if st[12] else "fast path: off"
+    fast = (f"heap-free merge: status {st[8]} workgroups {st[13]} repairs/merge {st[9] / n:.2f} re-publishes/merge "
+            f"{st[14] / n:.2f} cycles(pop, pass)/merge {[int(c / n) for c in st[10:12]]}") if st[12] else "heap-free merge: off"
     heap = (f"heap kernel: retries/merge {st[0] / n:.2f} heap-updates/merge {st[1] / n:.2f} overflows {st[2]} "
             f"cycles(find, wait, pass, replay)/merge {[int(c / n) for c in st[3:7]]}") if st[7] else "heap kernel: skipped"
     return fast + " | " + heap
@@ -39,17 +39,22 @@ def sweep(name, X, scipy_check):
         t = time.perf_counter()
         ref = linkage(pdist(X), "centroid")
         print(f"{name}: scipy pdist + linkage {1e3 * (time.perf_counter() - t):.0f} ms", flush=True)
-    for G in [int(g) for g in os.environ.get("LK_GS", "0,1,8,16").split(",")]:
-        # G = 0: the default (heap-free merge first); G >= 1: PA_LINKAGE_FAST=0, the heap kernel with G workgroups
-        if G == 0:
+    for G in [int(g) for g in os.environ.get("LK_GS", "0,-8,-16,1").split(",")]:
+        # G = 0: the default (heap-free merge first, its own choice of workgroups); G < 0: the heap-free merge forced
+        # to -G workgroups; G >= 1: PA_LINKAGE_FAST=0, the heap kernel with G workgroups
+        if G <= 0:
             os.environ.pop("PA_LINKAGE_FAST", None)
             os.environ.pop("PA_LINKAGE_WGS", None)
+            os.environ.pop("PA_LINKAGE_FAST_WGS", None)
+            if G < 0:
+                os.environ["PA_LINKAGE_FAST_WGS"] = str(-G)
             distance.linkage_centroid(X[:64].copy(), dev)
             torch.cuda.synchronize()
             t = time.perf_counter()
             Z = distance.linkage_centroid(X.copy(), dev)
             dt = time.perf_counter() - t
             info = describe(len(X))
+            os.environ.pop("PA_LINKAGE_FAST_WGS", None)
         else:
             os.environ["PA_LINKAGE_FAST"] = "0"
             Z, dt, info = run(X, G)
