@@ -23,20 +23,23 @@
 //     where the bound or the matrix entry changes (SciPy's comparison at the pop, made at the update).
 //   * the serial heap replay (sort + ~12 sifts by one lane): gone; the owner thread of row z updates min_dist[z] and
 //     neighbor[z] in LDS in place.
-//   * one CU's f64 divide / square-root and address rate: G workgroups (1 up to N = 10 240, 16 above) own the rows in
-//     interleaved chunks of 1 024 (row z: workgroup (z >> 10) % G, thread z & 1023); each keeps the state of ITS rows
-//     in LDS and does its share of every O(N) step.
+//   * one CU's f64 divide / square-root and address rate: G workgroups of 1 024 threads (1 up to N = 1 024, 8 up to
+//     12 000, 16 above) own the rows in interleaved chunks of 1 024 (row z: workgroup (z >> 10) % G, thread
+//     z & 1023); each keeps the state of ITS rows in LDS and does its share of every O(N) step.  (256-thread
+//     workgroups were measured SLOWER, profiles/r4_linkage_heap_free_v2_t256.txt: the pass and wave 0's serial
+//     reduction chain need the other waves of a SIMD to hide their dependent-issue latency.)
 // Exchange between the workgroups (one all-gather per step, no separate barrier): wave 0 of every workgroup writes a
 // 16-granule record -- its two smallest rows with neighbour / size, and its minimum of the row scan or of the new
 // row y -- as 8-byte {data, sequence tag} granules with sc1 stores and polls the records of all G workgroups with
 // sc1 loads until every tag carries the current sequence number (MI355X_MICROARCH.md, hand-off by tagged granules;
 // double-buffered by sequence parity; correct at any workgroup placement, fastest when the G workgroups share an
 // XCD, hence the launch of 8 G workgroups of which every 8th works).  Wave 0 of EVERY workgroup then holds the same
-// candidate table (lane 4g: best row of workgroup g, 4g+1: its second, 4g+2: its scan minimum, lane 3: the row
-// merged last, whose new bound only now is known) and pops from it without further traffic:
+// candidate table (lane 4g: best row of workgroup g, 4g+1: its second, 4g+3: the row it repaired last, lane 2: the
+// row merged last, whose new bound only now is known) and pops from it without further traffic:
 //   merge k:    pass over the own rows -> exchange -> pop -> [row scan -> exchange -> pop]* -> next merge
-// A lower-bound repair raises the bound of its row, so the second candidate of that workgroup is no longer known to
-// be its second smallest: if the next pop lands there on a DIFFERENT row, the candidates are re-published first.
+// A lower-bound repair raises the bound of its row, so that workgroup's two smallest rows are no longer known: with
+// the scan minimum it publishes its two smallest rows computed WITHOUT the repaired row, which from then on travels
+// as the workgroup's third table entry -- the table always contains the two smallest bounds overall.
 // Every poll is bounded (about 2 s): a workgroup that never shows up (not resident) ends the kernel with status 3
 // and the gated heap kernel takes over -- there is no way to hang.
 // hipcc-flags: -ffp-contract=off
@@ -193,7 +196,7 @@ struct LfWaveOut {       // per wave, LDS: its two smallest rows and its scan / 
   lf_u32 ib, pad3;
 };
 struct LfFinal {         // wave 0 -> every thread of the workgroup, LDS
-  int action;            // 0 merge, 1 repair (scan row x), 2 re-publish the candidates, 3 give up
+  int action;            // 0 merge, 1 repair (scan row x), 3 give up
   int fail;              // status code of action 3
   int x;
   lf_u32 nbx;
@@ -203,8 +206,8 @@ struct LfFinal {         // wave 0 -> every thread of the workgroup, LDS
   int pad;
   lf_u64 key, ap_key;
 };
-enum { LF_MERGE = 0, LF_REPAIR = 1, LF_REPUBLISH = 2, LF_FAIL = 3 };
-enum { LF_X_MAIN = 0, LF_X_SCAN = 1, LF_X_REPUB = 2 };   // what an exchange carries
+enum { LF_MERGE = 0, LF_REPAIR = 1, LF_FAIL = 3 };
+enum { LF_X_MAIN = 0, LF_X_SCAN = 1 };   // what an exchange carries: candidates + new row y / scan of row x
 
 // status word: 0 = dendrogram complete, 1 = tie at a pop (take the heap), 2 = degenerate input (no finite bound, or
 // more repairs than SciPy's loop allows), 3 = a workgroup never showed up -- anything but 0 lets the gated heap
@@ -263,36 +266,44 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
   }
   __syncthreads();
 
-  // ---- wave 0's candidate table (one entry per lane: 4g best of workgroup g, 4g+1 second, 4g+2 scan minimum, lane 3
-  // the row merged last) and per-workgroup flags on lane 4g
+  // ---- wave 0's candidate table, one entry per lane: 4g best row of workgroup g, 4g+1 its second (both computed
+  // WITHOUT the row merged last and without the row that workgroup repaired last), 4g+3 that repaired row, lane 2 the
+  // row merged last (lanes 4g+2 only carry the scan minima of an exchange)
   lf_u64 t_key = LF_INF;
   lf_u32 t_idx = 0xffffffffu, t_nb = NONE32, t_sz = 0;
-  int t_inval = 0;        // the second candidate of this workgroup is stale (a repair raised a bound)
-  lf_u32 t_rep = 0xffffffffu;   // ... the repaired row
+  // what this workgroup published last (re-sent unchanged while its rows do not change)
+  lf_u64 cb1k = LF_INF, cb2k = LF_INF;
+  lf_u32 cb1i = 0xffffffffu, cb1n = NONE32, cb1s = 0, cb2i = 0xffffffffu, cb2n = NONE32, cb2s = 0;
   lf_u32 seq = 0;         // exchange counter (tags; parity selects the mail / LDS buffers)
-  int tries = 0;          // pops of the current merge (SciPy allows n - k)
+  int tries = 0;          // lower-bound repairs of the current merge (SciPy's pop loop allows n - k - 1)
 
-  long long st_rep = 0, st_repub = 0, st_c0 = 0, st_c1 = 0;
+  long long st_rep = 0, st_c0 = 0, st_c1 = 0;
   int fail = 0;
   int k = 0;
   int pend_y = -1;                 // row merged last: its new bound arrives with the next exchange
   lf_u32 pend_size = 0;
   int pend_cid = 0;
-  int xmode = LF_X_REPUB;          // first exchange: plain candidates
+  int y_excl = -1;                 // ... and stays out of its workgroup's top-2 until the next merge (table lane 2)
+  int xmode = LF_X_MAIN;
   lf_u64 pb_key = LF_INF;          // this thread's minimum of the new row y / of the row scan
   lf_u32 pb_idx = 0xffffffffu;
   int scan_x = -1;                 // row being repaired (LF_X_SCAN)
+  lf_u32 scan_nx = 0;              // ... its size
   long long tc = __builtin_readcyclecounter();
 
   while (true) {
-    // ================= A. this thread's two smallest own rows (not for a scan exchange)
+    if (xmode == LF_X_MAIN) y_excl = pend_y;
+    // ================= A. this thread's two smallest own rows; in a scan exchange only the workgroup of the
+    // repaired row has anything new to say
+    const bool fresh = xmode == LF_X_MAIN || owner_wg(scan_x) == wg;
     lf_u64 k1 = LF_INF, k2 = LF_INF;
     lf_u32 i1 = 0xffffffffu, i2 = 0xffffffffu;
     int l1 = 0, l2 = 0;
-    if (xmode != LF_X_SCAN) {
+    if (fresh) {
       for (int c = 0; c < SL; ++c) {
         const int z = row_of(c), l = (c << LF_SH) + tid;
-        const lf_u64 kk = (xmode == LF_X_MAIN && z == pend_y) ? LF_INF : lf_key(mind_l[l]);
+        const bool skip = z == y_excl || (xmode == LF_X_SCAN && z == scan_x);
+        const lf_u64 kk = skip ? LF_INF : lf_key(mind_l[l]);
         if (kk < k1) {
           k2 = k1; i2 = i1; l2 = l1;
           k1 = kk; i1 = (lf_u32)z; l1 = l;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
     ++seq;
     {
       lf_u64 m;
-      if (xmode != LF_X_SCAN) {
+      if (fresh) {
         const int w1 = lf_wave_argmin(k1, i1, &m);
         if (lane == w1) {
           exch[pe][wave].k1 = k1;
@@ -325,22 +336,18 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
           exch[pe][wave].sz2 = kc < LF_INF ? (lf_u32)size_l[lc] : 0u;
         }
       }
-      if (xmode != LF_X_REPUB) {
-        const int wb = lf_wave_argmin(pb_key, pb_idx, &m);
-        if (lane == wb) {
-          exch[pe][wave].kb = pb_key;
-          exch[pe][wave].ib = pb_idx;
-        }
+      const int wb = lf_wave_argmin(pb_key, pb_idx, &m);
+      if (lane == wb) {
+        exch[pe][wave].kb = pb_key;
+        exch[pe][wave].ib = pb_idx;
       }
     }
     __syncthreads();
     // ================= C. wave 0: workgroup result -> exchange -> candidate table -> pop
     if (wave == 0) {
-      // -- workgroup top-2 (lanes 0-15: the waves' best, 16-31: their second) and scan minimum
-      lf_u64 b1k = LF_INF, b2k = LF_INF, pbk = LF_INF;
-      lf_u32 b1i = 0xffffffffu, b1n = NONE32, b1s = 0, b2i = 0xffffffffu, b2n = NONE32, b2s = 0, pbi = 0xffffffffu;
       lf_u64 m;
-      if (xmode != LF_X_SCAN) {
+      if (fresh) {
+        // workgroup top-2: lanes 0 .. W-1 hold the waves' best, 16 .. 16+W-1 their second
         lf_u64 ck = LF_INF;
         lf_u32 ci = 0xffffffffu, cn = NONE32, cs = 0;
         if (lane < LF_W) {
@@ -349,19 +356,21 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
           ck = exch[pe][lane - 16].k2; ci = exch[pe][lane - 16].i2; cn = exch[pe][lane - 16].nb2; cs = exch[pe][lane - 16].sz2;
         }
         const int w1 = lf_wave_argmin(ck, ci, &m);
-        b1k = m; b1i = lf_rl(ci, w1); b1n = lf_rl(cn, w1); b1s = lf_rl(cs, w1);
+        cb1k = m; cb1i = lf_rl(ci, w1); cb1n = lf_rl(cn, w1); cb1s = lf_rl(cs, w1);
         const lf_u64 ck2 = lane == w1 ? LF_INF : ck;
         const int w2 = lf_wave_argmin(ck2, ci, &m);
-        b2k = m; b2i = lf_rl(ci, w2); b2n = lf_rl(cn, w2); b2s = lf_rl(cs, w2);
+        cb2k = m; cb2i = lf_rl(ci, w2); cb2n = lf_rl(cn, w2); cb2s = lf_rl(cs, w2);
       }
-      if (xmode != LF_X_REPUB) {
+      lf_u64 pbk;
+      lf_u32 pbi;
+      {
         const lf_u64 ck = lane < LF_W ? exch[pe][lane].kb : LF_INF;
         const lf_u32 ci = lane < LF_W ? exch[pe][lane].ib : 0xffffffffu;
         const int wb = lf_wave_argmin(ck, ci, &m);
         pbk = m; pbi = lf_rl(ci, wb);
       }
       // -- exchange: this workgroup's record out, everybody's records in
-      lf_u64 c_key = LF_INF;    // this lane's table entry out of the records (lanes 4g, 4g+1, 4g+2)
+      lf_u64 c_key = LF_INF;    // this lane's part of the records (lanes 4g: best, 4g+1: second, 4g+2: scan minimum)
       lf_u32 c_idx = 0xffffffffu, c_nb = NONE32, c_sz = 0;
       int timeout = 0;
       if (MULTI) {
@@ -369,16 +378,16 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         if (lane < 16) {
           lf_u32 dta = 0;
           switch (lane) {
-            case 0: dta = (lf_u32)b1k; break;
-            case 1: dta = (lf_u32)(b1k >> 32); break;
-            case 2: dta = b1i; break;
-            case 3: dta = b1n; break;
-            case 4: dta = b1s; break;
-            case 5: dta = (lf_u32)b2k; break;
-            case 6: dta = (lf_u32)(b2k >> 32); break;
-            case 7: dta = b2i; break;
-            case 8: dta = b2n; break;
-            case 9: dta = b2s; break;
+            case 0: dta = (lf_u32)cb1k; break;
+            case 1: dta = (lf_u32)(cb1k >> 32); break;
+            case 2: dta = cb1i; break;
+            case 3: dta = cb1n; break;
+            case 4: dta = cb1s; break;
+            case 5: dta = (lf_u32)cb2k; break;
+            case 6: dta = (lf_u32)(cb2k >> 32); break;
+            case 7: dta = cb2i; break;
+            case 8: dta = cb2n; break;
+            case 9: dta = cb2s; break;
             case 10: dta = (lf_u32)pbk; break;
             case 11: dta = (lf_u32)(pbk >> 32); break;
             case 12: dta = pbi; break;
@@ -423,9 +432,9 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         }
       } else {
         if (lane == 0) {
-          c_key = b1k; c_idx = b1i; c_nb = b1n; c_sz = b1s;
+          c_key = cb1k; c_idx = cb1i; c_nb = cb1n; c_sz = cb1s;
         } else if (lane == 1) {
-          c_key = b2k; c_idx = b2i; c_nb = b2n; c_sz = b2s;
+          c_key = cb2k; c_idx = cb2i; c_nb = cb2n; c_sz = cb2s;
         } else if (lane == 2) {
           c_key = pbk; c_idx = pbi;
         }
@@ -436,47 +445,39 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
       lf_u32 ap_nbx = NONE32;
       lf_u64 ap_key = LF_INF;
       int f = timeout ? 3 : 0;
+      if (q == 0 || q == 1) {
+        t_key = c_key; t_idx = c_idx; t_nb = c_nb; t_sz = c_sz;
+      }
+      // minimum over the workgroups of the scanned row (scan exchange) / of the new row y (main exchange)
       lf_u64 m2;
+      const int wr = lf_wave_argmin(q == 2 ? c_key : LF_INF, c_idx, &m2);
+      const lf_u32 ri = lf_rl(c_idx, wr);
       if (xmode == LF_X_SCAN) {
-        // minimum of the scanned row over all workgroups = the repaired bound of row scan_x (table lane: its entry)
-        const int wr = lf_wave_argmin(q == 2 ? c_key : LF_INF, c_idx, &m2);
-        const lf_u32 ri = lf_rl(c_idx, wr);
+        // = the repaired bound of row scan_x, which now travels as the extra entry of its workgroup
         ap_row = scan_x;
         ap_key = m2;
         ap_nbx = m2 >= LF_INF ? NONE32 : (ri | EX32);
-        const bool mine = (q == 0 || q == 1) && t_idx == (lf_u32)scan_x && t_key < LF_INF;
-        if (mine) {
-          t_key = ap_key;
-          t_nb = ap_nbx;
-        }
-        const int og = owner_wg(scan_x);
-        if (lane == 4 * og) {
-          t_inval = 1;
-          t_rep = (lf_u32)scan_x;
+        if (lane == 4 * owner_wg(scan_x) + 3) {
+          t_key = ap_key; t_idx = (lf_u32)scan_x; t_nb = ap_nbx; t_sz = scan_nx;
         }
       } else {
-        if (q == 0 || q == 1) {
-          t_key = c_key; t_idx = c_idx; t_nb = c_nb; t_sz = c_sz;
-        }
-        if (q == 0) t_inval = 0;
-        if (lane == 3) t_key = LF_INF;
-        if (xmode == LF_X_MAIN && pend_y >= 0) {
-          // new bound of the row merged last: minimum of the new row over all workgroups (SciPy's loop 4)
-          const int wr = lf_wave_argmin(q == 2 ? c_key : LF_INF, c_idx, &m2);
-          const lf_u32 ri = lf_rl(c_idx, wr);
+        if (q == 3) t_key = LF_INF;
+        if (lane == 2) t_key = LF_INF;
+        if (pend_y >= 0) {
+          // = the new bound of the row merged last (SciPy's loop 4)
           ap_row = pend_y;
           if (pend_y < n - 1) {
             if (m2 >= LF_INF) f = f ? f : 2;
             ap_key = m2;
             ap_nbx = ri | EX32;
-            if (lane == 3) {
+            if (lane == 2) {
               t_key = m2; t_idx = (lf_u32)pend_y; t_nb = ap_nbx; t_sz = pend_size;
             }
           }
         }
       }
       // -- pop: smallest candidate, tie check against the runner-up
-      const bool is_cand = q == 0 || q == 1 || lane == 3;
+      const bool is_cand = q != 2 || lane == 2;
       const lf_u64 pk = is_cand ? t_key : LF_INF;
       lf_u64 mk;
       const int lw = lf_wave_argmin(pk, t_idx, &mk);
@@ -486,15 +487,9 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
       if (!f && mk2 == mk) f = 1;
       const int x = (int)lf_rl(t_idx, lw);
       const lf_u32 nbx = lf_rl(t_nb, lw), nx = lf_rl(t_sz, lw);
-      if (!f) {
-        const int inv = lw == 3 ? 0 : __builtin_amdgcn_readlane(t_inval, lw & ~3);
-        const lf_u32 rp = lf_rl(t_rep, lw & ~3);
-        if (inv && (lf_u32)x != rp) {
-          action = LF_REPUBLISH;
-        } else if ((nbx & EX32) == 0 || (nbx & NONE32) == NONE32) {
-          action = LF_REPAIR;
-          if (++tries >= n - k) f = 2;   // (SciPy's pop loop would run out: rare enough for the heap)
-        }
+      if (!f && ((nbx & EX32) == 0 || (nbx & NONE32) == NONE32)) {
+        action = LF_REPAIR;
+        if (++tries >= n - k) f = 2;   // (SciPy's pop loop would run out: rare enough for the heap)
       }
       if (f) action = LF_FAIL;
       if (lane == 0) {
@@ -533,11 +528,6 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
       fail = F.fail;
       break;
     }
-    if (F.action == LF_REPUBLISH) {
-      xmode = LF_X_REPUB;
-      ++st_repub;
-      continue;
-    }
     const int x = F.x;
     if (F.action == LF_REPAIR) {
       // find_min_dist(n, D, size, x): this thread's columns i > x of row x
@@ -564,6 +554,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         }
       }
       scan_x = x;
+      scan_nx = F.nx;
       xmode = LF_X_SCAN;
       ++st_rep;
       continue;
@@ -684,7 +675,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
       stats[3] = st_c1;
       stats[4] = n;
       stats[5] = G;
-      stats[6] = st_repub;
+      stats[6] = 0;
       stats[7] = k;
     }
   }
@@ -703,7 +694,7 @@ bool lf_wanted(int n) {
   if (e != nullptr && atoi(e) == 0) return false;
   const char* g = getenv("PA_LINKAGE_FAST_MAX_GB");
   const double cap = (g != nullptr && atof(g) > 0 ? atof(g) : 96.0) * 1e9;
-  return 8.0 * (double)n * (double)lf_ld(n) <= cap && n <= 147456;
+  return 8.0 * (double)n * (double)lf_ld(n) <= cap && n <= 150000;
 }
 
 // bytes the fast path adds to the linkage workspace: square matrix + initial candidates + sizes / ids + mail + status
@@ -713,14 +704,16 @@ size_t lf_workspace_bytes(int n) {
   return lf_align(8 * (size_t)n * (size_t)lf_ld(n)) + 3 * ni + nd + lf_align(2 * LF_MAXG * 16 * 8) + 256;
 }
 
-// workgroups of the merge: 1 while the row state fits one CU's LDS (14 B per row, N <= 10 240), 16 above.
-// PA_LINKAGE_FAST_WGS (2 ... 16) forces the multi-workgroup form (raised if the rows would not fit).
+// workgroups of the merge: 1 up to N = 1 024, 8 up to 12 000, 16 above (measured on MI355X, profiles/r4_linkage_*:
+// N = 7 000: 8 workgroups 109 ms, 16: 113 ms, 1: 170 ms; N = 20 000: 8: 407 ms, 16: 366 ms).
+// PA_LINKAGE_FAST_WGS (1 ... 16) overrides; raised when the rows of a workgroup would not fit its LDS.
 static int lf_num_workgroups(int n) {
   const int chunks = cdiv(n, LF_T);
   const char* e = getenv("PA_LINKAGE_FAST_WGS");
-  int G = (e != nullptr && atoi(e) >= 1) ? atoi(e) : (chunks <= 10 && n <= 32767 ? 1 : LF_MAXG);
+  int G = (e != nullptr && atoi(e) >= 1) ? atoi(e) : (n <= 1024 ? 1 : (n < 12000 ? 8 : LF_MAXG));
   if (G > LF_MAXG) G = LF_MAXG;
-  if (G == 1 && !(chunks <= 10 && n <= 32767)) G = 2;
+  if (G > chunks) G = chunks;
+  if (G == 1 && ((size_t)chunks * LF_T * 14 > LF_LDS_MAX || n > 32767)) G = 2;
   while (G > 1 && (size_t)cdiv(chunks, G) * LF_T * 16 > LF_LDS_MAX && G < LF_MAXG) ++G;
   return G;
 }

@@ -1,7 +1,7 @@
 """Python model of the heap-free centroid-linkage merge of csrc/linkage_fast.hip (test infrastructure): the same
 per-row state (lower bound, neighbour candidate, EXACT bit, size, id), the same update rules, the same candidate
-exchange between workgroups (every workgroup publishes its two smallest rows; a repaired row invalidates its
-workgroup's second candidate; the freshly merged row travels as a pseudo candidate), the same give-up rule (a pop
+exchange between workgroups (every workgroup publishes its two smallest rows; the workgroup of a repaired row
+re-publishes them without that row, which travels as an extra candidate; so does the freshly merged row), the same give-up rule (a pop
 whose smallest bound is attained twice -> None, the launcher then runs the heap kernel of csrc/linkage.hip).
 The CPU suite checks the MODEL against scipy.cluster.hierarchy.linkage(., "centroid")
 (tests/test_linkage_fast_model.py); the GPU suite checks the KERNEL against SciPy (tests/test_pipeline_gpu.py)."""
@@ -11,9 +11,11 @@ from scipy.spatial.distance import pdist, squareform
 INF = np.inf
 
 
-def fast_linkage_model(X, G=1, CH=1024, stats=None):
+def fast_linkage_model(X, G=1, CH=256, stats=None):
     """-> (Z or None, merge index of the give-up or number of lower-bound repairs).  G workgroups own the rows in
-    interleaved chunks of CH rows (row z belongs to workgroup (z // CH) % G)."""
+    interleaved chunks of CH rows (row z belongs to workgroup (z // CH) % G).  Candidate table: per workgroup its two
+    smallest rows (computed without the row merged last and without the row it is repairing) + one extra entry (the
+    row repaired last in that workgroup), + the row merged last."""
     n = len(X)
     S = squareform(pdist(X))
     size = np.ones(n, int)
@@ -30,67 +32,55 @@ def fast_linkage_model(X, G=1, CH=1024, stats=None):
     owner = lambda z: (z // CH) % G
     rows_of = [[z for z in range(n) if owner(z) == g] for g in range(G)]
     Z = np.zeros((n - 1, 4))
-    reps = republishes = 0
+    reps = 0
 
     def local_top2(g, exclude):
-        c = sorted((mind[z], z) for z in rows_of[g] if z != exclude and mind[z] < INF)
+        c = sorted((mind[z], z) for z in rows_of[g] if z not in exclude and mind[z] < INF)
         return (c + [None, None])[:2]
 
-    pend_y = -1
-    passbest = None
+    pend_y, passbest = -1, None
     k = 0
-    mode = "main"
-    cand = [[None, None] for _ in range(G)]
-    inval = [False] * G
-    rep = [-1] * G
-    yentry = None
-    tries = 0
     while k < n - 1:
-        if mode in ("main", "republish"):
-            for g in range(G):
-                cand[g] = local_top2(g, pend_y if mode == "main" else -1)
-                inval[g] = False
-            yentry = None
-            if mode == "main" and pend_y >= 0:
-                d, i = passbest
-                if pend_y < n - 1:
-                    if i < 0:
-                        return None, k
-                    mind[pend_y], nb[pend_y], ex[pend_y] = d, i, True
-                    yentry = (d, pend_y)
-                pend_y = -1
-            if mode == "republish":
-                republishes += 1
-        # ---- pop
-        C = [(c[0], c[1], g) for g in range(G) for c in cand[g] if c is not None]
-        if yentry is not None:
-            C.append((yentry[0], yentry[1], -1))
-        C.sort()
-        if not C:
-            return None, k
-        if len(C) > 1 and C[1][0] == C[0][0]:
-            return None, k                      # tie at the pop: take the heap
-        dist, x, g = C[0]
-        if g >= 0 and inval[g] and x != rep[g]:
-            mode = "republish"
-            continue
-        y = nb[x]
-        if not (ex[x] and y >= 0):
-            tries += 1
-            if tries > n - k:
+        # ---- main exchange: everybody's two smallest rows (without the row merged last) + that row's new bound
+        y_excl = pend_y
+        top2 = [local_top2(g, (y_excl,)) for g in range(G)]
+        extra = [None] * G
+        yentry = None
+        if pend_y >= 0:
+            d, i = passbest
+            if pend_y < n - 1:
+                if i < 0:
+                    return None, k
+                mind[pend_y], nb[pend_y], ex[pend_y] = d, i, True
+                yentry = (d, pend_y)
+            pend_y = -1
+        tries = 0
+        while True:
+            C = [c for g in range(G) for c in top2[g] + [extra[g]] if c is not None]
+            if yentry is not None:
+                C.append(yentry)
+            C.sort()
+            if not C:
                 return None, k
+            if len(C) > 1 and C[1][0] == C[0][0]:
+                return None, k                      # tie at the pop: take the heap
+            dist, x = C[0]
+            y = nb[x]
+            if ex[x] and y >= 0:
+                break
+            tries += 1
+            if tries >= n - k:
+                return None, k
+            # ---- scan exchange: repaired bound of row x; its workgroup publishes a fresh top-2 without x
             best, bi = INF, -1
             for i in range(x + 1, n):
                 if size[i] and S[x, i] < best:
                     best, bi = S[x, i], i
             nb[x], mind[x], ex[x] = bi, best, bi >= 0
             reps += 1
-            which = 0 if (cand[g][0] is not None and cand[g][0][1] == x) else 1
-            cand[g][which] = (best, x) if bi >= 0 else None
-            inval[g], rep[g] = True, x
-            mode = "pop"
-            continue
-        tries = 0
+            g = owner(x)
+            top2[g] = local_top2(g, (y_excl, x))
+            extra[g] = (best, x) if bi >= 0 else None
         # ---- merge
         nx, ny = size[x], size[y]
         a, b = sorted((cid[x], cid[y]))
@@ -115,12 +105,10 @@ def fast_linkage_model(X, G=1, CH=1024, stats=None):
         size[x] = 0
         size[y] = nx + ny
         cid[y] = n + k
-        mind[y] = INF          # (the row's new bound arrives with the next exchange)
         pend_y, passbest = y, (best, bi)
         k += 1
-        mode = "main"
     if stats is not None:
-        stats.update(repairs=reps, republishes=republishes)
+        stats.update(repairs=reps)
     return Z, reps
 
 

@@ -150,12 +150,13 @@ def test_linkage_multi_workgroup_vs_scipy(gpu_device, n, workgroups, monkeypatch
 
 
 @pytest.mark.parametrize("n,d,wgs", [(3, 8, None), (700, 16, None), (4000, 64, None), (7176, 256, None),
-                                     (12300, 32, None), (700, 16, 3), (4000, 64, 8), (7176, 256, 16), (12300, 32, 5)])
+                                     (12300, 32, None), (700, 16, 3), (4000, 64, 2), (7176, 256, 16), (7176, 256, 1),
+                                     (12300, 32, 5)])
 def test_linkage_heap_free_merge_vs_scipy(gpu_device, n, d, wgs, monkeypatch):
     """csrc/linkage_fast.hip (arg-min over the lower bounds instead of SciPy's heap, EXACT bit per row, square
     matrix, candidate exchange between workgroups) on tie-free data: it completes the dendrogram by itself (status
     0, the heap kernel returns at its gate) and the result is bit-identical to SciPy.  N = 7 176 is one audio-hour
-    (one workgroup by default), 12 300 takes 16 workgroups by default; `wgs` forces the multi-workgroup form."""
+    (8 workgroups by default), 12 300 takes 16, up to 1 024 rows one; `wgs` forces a number of workgroups."""
     from scipy.cluster.hierarchy import linkage
     from scipy.spatial.distance import pdist
     from pyannote_audio_amd import distance
@@ -171,7 +172,7 @@ def test_linkage_heap_free_merge_vs_scipy(gpu_device, n, d, wgs, monkeypatch):
     bad = np.nonzero((got != want).any(axis=1))[0]
     assert len(bad) == 0, f"first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]} (status {st[8]})"
     assert st[8] == 0 and st[7] == 0, f"heap-free merge did not complete: status {st[8]}, heap kernel n {st[7]}"
-    assert st[13] == (wgs if wgs is not None else (1 if n <= 10240 else 16))
+    assert st[13] == (wgs if wgs is not None else (1 if n <= 1024 else (8 if n < 12000 else 16)))
 
 
 @pytest.mark.parametrize("wgs", [None, 4])
