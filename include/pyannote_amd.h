@@ -328,16 +328,25 @@ int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream);
 int pa_cdist_cosine_f64(const double* A, int NA, const double* B, int NB, int D, double* out,
                         double* norms, void* stream);
 
+/* Cluster centroids, bit-identical to np.mean(X[rows of cluster k], axis=0) (pipelines/clustering.py:182-187,
+ * :462-472: float32 row-order sums divided in float32).  X: (., D) float32 rows; rows: row numbers grouped by
+ * cluster, original order inside a cluster; offsets: K + 1 group boundaries into `rows`; out: (K, D) float32, NaN
+ * rows for empty clusters. */
+int pa_centroid_means(const float* X, int D, const int* rows, const int* offsets, int K, float* out, void* stream);
+
 /* Centroid-linkage dendrogram, bit-identical to scipy.cluster.hierarchy.linkage(y, "centroid")
  * (pipelines/clustering.py:374-382).  D: condensed distances (n*(n-1)/2 doubles, e.g. straight from
- * pa_pdist_f64), OVERWRITTEN;  Z: (n-1, 4) doubles in SciPy's layout [id_a, id_b, height, size]. */
+ * pa_pdist_f64), OVERWRITTEN when the heap kernel runs;  Z: (n-1, 4) doubles in SciPy's layout [id_a, id_b,
+ * height, size].  Two kernels behind one call (csrc/linkage_fast.hip, csrc/linkage.hip): a heap-free merge on a
+ * square copy of the matrix over 1 / 8 / 16 workgroups, and -- only when two rows ever tie for the smallest lower
+ * bound, i.e. when SciPy's heap order would matter -- the exact replay of SciPy's heap on the condensed matrix.
+ * The workspace holds the square copy (8 n^2 bytes; PA_LINKAGE_FAST_MAX_GB caps it, default 96). */
 size_t pa_linkage_workspace_bytes(int n);
 int pa_linkage_centroid_f64(double* D, int n, double* Z, void* workspace, size_t workspace_bytes,
                             void* stream);
-/* The same merge with a placement hint: `alone` != 0 says that nothing else competes for the GPU while it runs (one
- * file applied on its own, the last file of a batch), and the merge of one audio-hour (6 000 <= n < 12 000) then
- * spreads its O(n) pass over 8 workgroups of one XCD (183 instead of 195 ms at n = 7 176); beside another file's
- * front end one workgroup disturbs less.  Results are identical either way. */
+/* The same with the placement hint of earlier rounds (`alone`: nothing else competes for the GPU); since round 4
+ * the hint is ignored -- the number of workgroups only depends on n (PA_LINKAGE_FAST_WGS / PA_LINKAGE_WGS
+ * override it for experiments).  Results are identical either way. */
 int pa_linkage_centroid_f64_ex(double* D, int n, double* Z, void* workspace, size_t workspace_bytes, int alone,
                                void* stream);
 

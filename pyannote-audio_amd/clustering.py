@@ -12,7 +12,9 @@ What runs where
                              of the reference's per-cluster / per-iteration Python loops:
                                * `segment_means`: all cluster centroids from one stable sort (contiguous
                                  slices instead of K boolean masks), bit-identical to
-                                 `np.mean(X[labels == k], axis=0)`
+                                 `np.mean(X[labels == k], axis=0)`; on a GPU the centroids of the final
+                                 assignment come from `distance.centroid_means` (`pa_centroid_means`: the
+                                 same sums in the same order on the embeddings that are still in HBM)
                                * `Dendrogram.large_cluster_counts`: the number of large clusters after
                                  EVERY merge from one O(N) scan of the merge sizes, which turns the
                                  reference's forced-number search (one `fcluster` per candidate cut,
@@ -29,6 +31,7 @@ from enum import Enum
 from typing import Optional, Tuple
 
 import numpy as np
+import torch
 from scipy.cluster.hierarchy import fcluster, linkage
 from scipy.spatial.distance import cdist as scipy_cdist
 
@@ -157,8 +160,17 @@ class BaseClustering(Pipeline):
                           constrained: bool = False, device_embeddings=None):
         """centroid of every cluster from the (un-normalised) training embeddings, then every
         (chunk, speaker) goes to its most similar centroid (clustering.py:142-212)"""
-        centroids = segment_means(embeddings[train_chunk_idx, train_speaker_idx], train_clusters,
-                                  int(np.max(train_clusters)) + 1)
+        K = int(np.max(train_clusters)) + 1
+        C, S, D = embeddings.shape
+        on_gpu = getattr(self.device, "type", None) == "cuda"
+        if (on_gpu and device_embeddings is not None and tuple(device_embeddings.shape) == (C, S, D)
+                and device_embeddings.dtype == torch.float32):
+            # the embeddings are still in HBM: centroids there (pa_centroid_means), only (K, D) comes back
+            centroids = distance.centroid_means(device_embeddings.reshape(C * S, D).contiguous(),
+                                                train_chunk_idx * S + train_speaker_idx, train_clusters, K,
+                                                self.device)
+        else:
+            centroids = segment_means(embeddings[train_chunk_idx, train_speaker_idx], train_clusters, K)
         soft = self._similarities(embeddings, centroids, device_embeddings)
         hard = self.constrained_argmax(soft) if constrained else np.argmax(soft, axis=2)
         return hard, soft, centroids

@@ -113,9 +113,51 @@ __global__ __launch_bounds__(128) void k_cdist_cosine_f64(const double* __restri
   }
 }
 
+// Cluster centroids (reference: pipelines/clustering.py:182-187 and :462-472,
+//   centroids = np.vstack([np.mean(train_embeddings[train_clusters == k], axis=0) for k in range(K)])).
+// numpy reduces a C-contiguous (n, D) float32 block over axis 0 row by row -- out[d] += row[d], top to bottom, in
+// float32 -- and np.mean divides by n in float32.  Here cluster k owns rows[offsets[k] .. offsets[k+1]) (row numbers
+// into X, in their original order: the host groups them with ONE stable sort) and a thread owns one column d: the
+// same additions in the same order; the loads of eight rows are in flight together, the adds stay sequential.
+// An empty cluster yields NaN (np.mean of an empty selection).  grid = (K, ceil(D / 256)), block = 256.
+__global__ __launch_bounds__(256) void k_centroid_means(const float* __restrict__ X, int D,
+                                                         const int* __restrict__ rows,
+                                                         const int* __restrict__ offsets,
+                                                         float* __restrict__ out) {
+  const int k = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
+  if (d >= D) return;
+  const int a = offsets[k], b = offsets[k + 1];
+  if (a >= b) {
+    out[(long)k * D + d] = __builtin_nanf("");
+    return;
+  }
+  float acc = X[(long)rows[a] * D + d];   // (np.add.reduce starts from the first row, not from 0)
+  int j = a + 1;
+  for (; j + 8 <= b; j += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = X[(long)rows[j + u] * D + d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = acc + v[u];
+  }
+  for (; j < b; ++j) acc = acc + X[(long)rows[j] * D + d];
+  out[(long)k * D + d] = acc / (float)(b - a);
+}
+
 }  // namespace pa
 
 extern "C" {
+
+// means of the rows of X (float32, row-major, D columns) selected by rows[offsets[k] .. offsets[k+1]) for every
+// cluster k < K, in that order; bit-identical to np.mean(X[rows of k], axis=0).  out: (K, D) float32.
+int pa_centroid_means(const float* X, int D, const int* rows, const int* offsets, int K, float* out, void* stream) {
+  if (K <= 0 || D <= 0) return 0;
+  pa::ProfScope prof("k_centroid_means", stream, 0.0, 0.0);
+  hipLaunchKernelGGL(pa::k_centroid_means, dim3(K, pa::cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, X, D, rows,
+                     offsets, out);
+  PA_CHECK_LAUNCH("pa_centroid_means");
+  return 0;
+}
 
 // scipy.spatial.distance.pdist(X, "euclidean"): condensed upper triangle, row-major pair order
 int pa_pdist_f64(const double* X, int N, int D, double* out, void* stream) {

@@ -18,20 +18,17 @@ from scipy.spatial.distance import pdist as _scipy_pdist
 from . import ffi
 
 def _use_gpu(device, n: int) -> bool:
-    """GPU kernels whenever the clustering object lives on a GPU (`pipeline.to(cuda)`).  There is no
-    silent downgrade: an object that was never placed (device None) RAISES, and a missing library on a
-    GPU device raises.  Only a clustering object that its user EXPLICITLY put on the host --
-    `clustering.to(torch.device("cpu"))`, stand-alone use outside the pipeline (the pipeline itself refuses
-    to run there: SpeakerDiarization._require_device) -- calls SciPy, i.e. the reference's own implementation
-    of these two functions; the CPU suite uses that to check the host-side cluster logic."""
+    """GPU kernels whenever the clustering object lives on a GPU (`pipeline.to(cuda)`); a missing library on a GPU
+    device raises -- no silent downgrade there.  A clustering object that was never placed (device None) or that
+    its user put on the host is the reference's stand-alone use (`AgglomerativeClustering().instantiate(...)(
+    embeddings, ...)`, pipelines/clustering.py:214-289) and calls SciPy, i.e. the reference's own implementation
+    of these two functions; the PIPELINE never gets there: SpeakerDiarization._require_device refuses to run
+    anywhere but on a GPU."""
     kind = getattr(device, "type", None)
     if kind == "cuda":
         ffi.require_gpu()
         return n >= 2
-    if kind == "cpu":
-        return False
-    raise RuntimeError("clustering distances: no device set -- move the pipeline / clustering object to an "
-                       "MI355X with .to(torch.device('cuda')); this package has no implicit CPU path")
+    return False
 
 
 @ffi.on_device(lambda X, device=None: device)
@@ -44,6 +41,30 @@ def pdist_euclidean(X: np.ndarray, device=None) -> np.ndarray:
     Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device)
     out = torch.empty(n * (n - 1) // 2, dtype=torch.float64, device=device)
     ffi.check(lib.pa_pdist_f64(ffi.ptr(Xd), n, X.shape[1], ffi.ptr(out), ffi.stream()), "pa_pdist_f64")
+    return out.cpu().numpy()
+
+
+@ffi.on_device(lambda X, rows, labels, num_segments, device: device)
+def centroid_means(X: torch.Tensor, rows: np.ndarray, labels: np.ndarray, num_segments: int, device) -> np.ndarray:
+    """means of the rows X[rows] per label 0..num_segments-1 on the GPU (`pa_centroid_means`), bit-identical to
+    `np.vstack([np.mean(X[rows][labels == k], axis=0) for k in range(num_segments)])` (pipelines/clustering.py:
+    182-187): ONE stable sort groups the row numbers (original order kept inside a cluster), the kernel adds the
+    rows of a cluster top to bottom in float32 and divides in float32.  `X`: (., D) float32 tensor on `device`
+    (the embeddings never leave HBM for this); an empty cluster yields NaN."""
+    ffi.require_gpu()
+    lib = ffi.load()
+    if X.dtype != torch.float32 or not X.is_contiguous():
+        raise ValueError("centroid_means: X must be a contiguous float32 tensor")
+    order = np.argsort(labels, kind="stable")
+    counts = np.bincount(labels, minlength=num_segments)[:num_segments]
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    grouped = np.ascontiguousarray(np.asarray(rows)[order], dtype=np.int32)
+    D = X.shape[1]
+    rows_d = torch.from_numpy(grouped).to(device)
+    offs_d = torch.from_numpy(offsets).to(device)
+    out = torch.empty((num_segments, D), dtype=torch.float32, device=device)
+    ffi.check(lib.pa_centroid_means(ffi.ptr(X), D, ffi.ptr(rows_d), ffi.ptr(offs_d), num_segments, ffi.ptr(out),
+                                    ffi.stream()), "pa_centroid_means")
     return out.cpu().numpy()
 
 

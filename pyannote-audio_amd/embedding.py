@@ -29,6 +29,26 @@ class EmbeddingEngine:
         self._ws = None
         self._idx_cache: dict = {}
 
+    # share of the device's FREE memory one launch group's workspace may take (several pipelines / processes on one
+    # GPU, or a smaller device, must not run out where the 2 048-chunk default asks for ~62 GB)
+    MAX_FREE_FRACTION = 0.4
+
+    def _group_size(self, num_chunks: int, num_samples: int, S: int) -> int:
+        """chunks per launch group: `max_chunks`, the file split EVENLY over the groups, and halved until the
+        workspace fits MAX_FREE_FRACTION of what is free right now (a cached workspace counts as free)."""
+        lib = ffi.load()
+        groups = -(-num_chunks // self.max_chunks)
+        per_group = -(-num_chunks // groups)
+        free, _ = torch.cuda.mem_get_info(self.pack.device)
+        # + what torch's caching allocator holds without using it, + this engine's own cached workspace
+        free += torch.cuda.memory_reserved(self.pack.device) - torch.cuda.memory_allocated(self.pack.device)
+        free += self._ws.numel() if self._ws is not None else 0
+        while per_group > 8 and lib.pa_emb_workspace_bytes(self.pack.struct, per_group, num_samples, S) > \
+                self.MAX_FREE_FRACTION * free:
+            groups *= 2
+            per_group = -(-num_chunks // groups)
+        return per_group
+
     def _workspace(self, nbytes: int) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
@@ -68,8 +88,7 @@ class EmbeddingEngine:
             masks = masks.to(dev, torch.float32).contiguous()
         emb = torch.empty((num_chunks, S, w.embed_dim), dtype=torch.float32, device=dev)
         c0 = 0
-        groups = -(-num_chunks // self.max_chunks)
-        per_group = -(-num_chunks // groups)
+        per_group = self._group_size(num_chunks, num_samples, S)
         while c0 < num_chunks:
             nb = min(per_group, num_chunks - c0)
             ws = self._workspace(lib.pa_emb_workspace_bytes(w, nb, num_samples, S))

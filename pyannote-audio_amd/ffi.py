@@ -177,6 +177,7 @@ _OPTIONAL: list[tuple] = [
     ("pa_gather_s2", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_pdist_f64", [c_fp, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_cdist_cosine_f64", [c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
+    ("pa_centroid_means", [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_linkage_workspace_bytes", [C.c_int], C.c_size_t),
     ("pa_linkage_centroid_f64", [c_fp, C.c_int, c_fp, c_fp, C.c_size_t, c_fp], C.c_int),
     ("pa_linkage_centroid_f64_ex", [c_fp, C.c_int, c_fp, c_fp, C.c_size_t, C.c_int, c_fp], C.c_int),

@@ -7,7 +7,8 @@ latency bound on the 7 x 153 GB/s xGMI mesh).  Two partitions share the record f
 
   * one long file: rank r processes the contiguous chunk range [r*C/G, (r+1)*C/G) (`all_gather_chunks`);
   * many files (BASELINE.json configs[4]): every rank diarizes its own files and all ranks exchange the
-    records of ALL files for one joint clustering (`all_gather_files`).
+    records of ALL files for one joint clustering (`all_gather_files`: ONE all-gather per job in steady state --
+    the per-file chunk counts travel in a fixed header inside the same buffer).
 
 The send buffer is assembled on the device from the tensors the kernels produced and, with RCCL, never
 leaves HBM; with gloo (CPU tests) it is staged through host memory because gloo cannot read device
@@ -107,39 +108,68 @@ def all_gather_chunks(seg_local, emb_local, total_chunks: int, shard: Shard, dev
     return unpack_records(torch.cat(parts, dim=0), F, S, D)
 
 
-def all_gather_files(records: Sequence[torch.Tensor], shard: Shard, device: torch.device
-                     ) -> List[List[torch.Tensor]]:
-    """Many files.  `records`: this rank's per-file (C_f, R) uint8 record tensors.  Returns, on every
-    rank, result[r][j] = records of the j-th file of rank r.  Two collectives: a tiny all-gather of the
-    chunk counts, then ONE all-gather of the concatenated records padded to the largest rank."""
-    counts = torch.tensor([r.shape[0] for r in records], dtype=torch.int64)
-    nfiles = torch.tensor([len(records)], dtype=torch.int64)
+MAX_FILES_PER_RANK = 61          # header capacity: 3 + 61 int64 = 512 bytes in front of the records
+_HEADER_BYTES = 8 * (3 + MAX_FILES_PER_RANK)
+_capacity: dict = {}              # (group, record bytes) -> chunks per rank every rank has agreed on
+collectives_issued = 0            # (tests) all-gathers issued by this module
+
+
+def _agreed_capacity(chunks: int) -> int:
+    """capacity every rank derives from the same number: the next multiple of 512 chunks above `chunks` + 12 %
+    (files of a stream are about the same length: one 1-hour file is 3 591 chunks -> 4 096)"""
+    return -(-int(chunks * 1.125 + 1) // 512) * 512
+
+
+def all_gather_files(records: Sequence[torch.Tensor], shard: Shard, device: torch.device,
+                     record_bytes: Optional[int] = None) -> List[List[torch.Tensor]]:
+    """Many files.  `records`: this rank's per-file (C_f, R) uint8 record tensors.  Returns, on every rank,
+    result[r][j] = records of the j-th file of rank r.
+
+    ONE all-gather per call in steady state: a rank's buffer is a fixed 512-byte header {overflow flag, number of
+    files, chunks wanted, chunks of file 0, 1, ...} followed by its records, padded to a capacity (chunks per rank)
+    that all ranks already agree on -- it is derived from the largest rank of an earlier call, so every rank
+    computes the same number without talking.  The very first call of a process group (no capacity yet), and a call
+    in which some rank's files outgrow the capacity (that rank sends its header with the overflow flag and no
+    records; every rank sees it, raises the capacity to the same new value and repeats), take TWO.
+    `record_bytes`: R, for a rank that has no file of its own (all ranks run the same models)."""
+    global collectives_issued
+    if len(records) > MAX_FILES_PER_RANK:
+        raise ValueError(f"at most {MAX_FILES_PER_RANK} files per rank and exchange")
+    R = int(records[0].shape[1]) if len(records) else int(record_bytes or 0)
+    if R <= 0:
+        raise ValueError("all_gather_files: record size unknown (no local file and no `record_bytes`)")
+    counts = [int(r.shape[0]) for r in records]
+    need = sum(counts)
+    key = (id(shard.group), R)
     wire = _wire_device(shard, device)
-    all_n = torch.empty(shard.world_size, dtype=torch.int64, device=wire)
-    dist.all_gather_into_tensor(all_n, nfiles.to(wire), group=shard.group)
-    fmax = int(all_n.max().item())
-    cnt = torch.zeros(fmax, dtype=torch.int64)
-    cnt[:len(records)] = counts
-    all_cnt = torch.empty((shard.world_size, fmax), dtype=torch.int64, device=wire)
-    dist.all_gather_into_tensor(all_cnt.view(-1), cnt.to(wire), group=shard.group)
-    all_cnt = all_cnt.cpu()
-    cmax = int(all_cnt.sum(dim=1).max().item())
-    R = records[0].shape[1] if len(records) else 0
-    Rt = torch.tensor([R], dtype=torch.int64)
-    all_R = torch.empty(shard.world_size, dtype=torch.int64, device=wire)
-    dist.all_gather_into_tensor(all_R, Rt.to(wire), group=shard.group)
-    R = int(all_R.max().item())
-    mine = torch.cat(list(records), dim=0) if len(records) else torch.zeros((0, R), dtype=torch.uint8,
-                                                                           device=device)
-    if mine.shape[0] < cmax:
-        mine = torch.cat([mine, mine.new_zeros((cmax - mine.shape[0], R))], dim=0)
-    recv = all_gather_records(mine.to(device), shard)
+    while True:
+        cap = _capacity.get(key, 0)
+        fits = need <= cap
+        header = torch.zeros(3 + MAX_FILES_PER_RANK, dtype=torch.int64)
+        header[0] = 0 if fits else 1
+        header[1] = len(records)
+        header[2] = need
+        header[3:3 + len(counts)] = torch.tensor(counts, dtype=torch.int64)
+        buf = torch.zeros(_HEADER_BYTES + cap * R, dtype=torch.uint8, device=device)
+        buf[:_HEADER_BYTES] = header.view(torch.uint8).to(device)
+        if fits and need:
+            buf[_HEADER_BYTES:_HEADER_BYTES + need * R] = torch.cat([r.to(device) for r in records], dim=0).reshape(-1)
+        send = buf if buf.device == wire else buf.to(wire)
+        recv = torch.empty((shard.world_size, send.numel()), dtype=torch.uint8, device=wire)
+        dist.all_gather_into_tensor(recv.view(-1), send, group=shard.group)
+        collectives_issued += 1
+        heads = recv[:, :_HEADER_BYTES].cpu().contiguous().view(torch.int64).reshape(shard.world_size, -1)
+        if int(heads[:, 0].max().item()) == 0:
+            break
+        _capacity[key] = _agreed_capacity(int(heads[:, 2].max().item()))   # the same on every rank
+    if recv.device != device:
+        recv = recv.to(device)
     out: List[List[torch.Tensor]] = []
     for r in range(shard.world_size):
-        files, pos = [], 0
-        for j in range(int(all_n[r].item())):
-            c = int(all_cnt[r, j].item())
-            files.append(recv[r, pos:pos + c])
-            pos += c
+        files, pos = [], _HEADER_BYTES
+        for j in range(int(heads[r, 1].item())):
+            c = int(heads[r, 3 + j].item())
+            files.append(recv[r, pos:pos + c * R].reshape(c, R))
+            pos += c * R
         out.append(files)
     return out

@@ -556,9 +556,12 @@ class SpeakerDiarization(Pipeline):
         if shard.world_size > 1:
             records = [parallel.pack_records(fr.dev_seg, fr.dev_emb) for fr in voiced]
             # (F, S) travel implicitly: all ranks run the same models
-            gathered = parallel.all_gather_files(records, shard, device)
-            if not F:
-                raise RuntimeError("joint clustering: this rank has no voiced file to infer shapes from")
+            if not F:       # this rank has no voiced file of its own: shapes from the model (all ranks run the same)
+                model = self._segmentation.model
+                window = int(round(self._chunk_grid().duration * self._audio.sample_rate))
+                F, S = int(model.num_frames(window)), len(model.specifications.classes)
+            # ONE all-gather in steady state (the per-file chunk counts travel inside the buffer)
+            gathered = parallel.all_gather_files(records, shard, device, record_bytes=F * S + 4 * S * D)
             segs, embs, owner = [], [], []
             for r, per_rank in enumerate(gathered):
                 for j, rec in enumerate(per_rank):
@@ -571,8 +574,9 @@ class SpeakerDiarization(Pipeline):
             segs = [fr.dev_seg for fr in voiced]
             embs = [fr.dev_emb for fr in voiced]
             mine = list(range(len(voiced)))
-        job.update(sizes=[s.shape[0] for s in segs], mine=mine,
-                   all_seg=torch.cat(segs, dim=0).contiguous(), all_emb=torch.cat(embs, dim=0).cpu().numpy())
+        all_emb_dev = torch.cat(embs, dim=0).contiguous()
+        job.update(sizes=[s.shape[0] for s in segs], mine=mine, all_seg=torch.cat(segs, dim=0).contiguous(),
+                   all_emb=all_emb_dev.cpu().numpy(), all_emb_dev=all_emb_dev)
         torch.cuda.current_stream(device).synchronize()   # the second half may run on another stream
         return job
 
@@ -591,7 +595,7 @@ class SpeakerDiarization(Pipeline):
         hard, _, centroids = self.clustering(
             embeddings=all_emb, segmentations=seg_view, num_clusters=num_speakers,
             min_clusters=min_speakers, max_clusters=max_speakers, frames=self._frames,
-            num_clean_frames=clean.cpu().numpy())
+            num_clean_frames=clean.cpu().numpy(), device_embeddings=job.get("all_emb_dev"))
         offsets = np.concatenate([[0], np.cumsum(sizes)])
         self.joint_hard_clusters = hard                # (sum C, S): kept for inspection / tests
         self.joint_sizes = sizes

@@ -202,10 +202,21 @@ def wav2vec_config(wav2vec) -> dict:
     """hyper-parameter `wav2vec` of SSeRiouSS (a bundle name, or the keyword arguments of
     torchaudio.models.wav2vec2_model) -> architecture description"""
     if isinstance(wav2vec, str):
-        if wav2vec not in WAV2VEC_BUNDLES:
-            raise NotImplementedError(f"wav2vec bundle {wav2vec!r}: built are {sorted(WAV2VEC_BUNDLES)} and "
-                                      "explicit wav2vec2_model configurations")
-        return dict(WAV2VEC_BUNDLES[wav2vec])
+        if wav2vec in WAV2VEC_BUNDLES:
+            return dict(WAV2VEC_BUNDLES[wav2vec])
+        import os
+        if os.path.isfile(wav2vec):
+            # a self-supervised checkpoint {"config": wav2vec2_model kwargs, "state_dict": ...}
+            # (SSeRiouSS.py:111-119); its weights are superseded by the model checkpoint's own `wav2vec.*` entries,
+            # only the architecture is read here
+            checkpoint = torch.load(wav2vec, map_location="cpu", weights_only=False)
+            if "config" not in checkpoint:
+                raise ValueError(f"wav2vec checkpoint {wav2vec!r} has no 'config' entry (SSeRiouSS.py:113)")
+            wav2vec = checkpoint["config"]
+        else:
+            raise NotImplementedError(f"wav2vec {wav2vec!r}: neither one of the built torchaudio bundles "
+                                      f"{sorted(WAV2VEC_BUNDLES)} nor the path of a checkpoint with a 'config' entry; "
+                                      "explicit wav2vec2_model configurations (a dict) work too")
     cfg = dict(wav2vec)
     cfg.setdefault("extractor_conv_layer_config", None)
     if cfg["extractor_conv_layer_config"] is None:
@@ -321,6 +332,9 @@ class SSeRiouSSPack:
             Lw.ln2_g, Lw.ln2_b = up(sd[f"{lp}.final_layer_norm.weight"]), up(sd[f"{lp}.final_layer_norm.bias"])
         self.rel_attn_embed = sd.get(f"{enc}.transformer.layers.0.attention.rel_attn_embed.weight")
         w.use_layer = int(hparams.get("wav2vec_layer", -1))
+        if w.use_layer == 0 or w.use_layer > nl:
+            # torchaudio's extract_features(num_layers=0) raises the same way when the reference's forward runs
+            raise ValueError(f"`num_layers` must be between [1, {nl}]")
         if w.use_layer < 0:
             mix = torch.softmax(sd["wav2vec_weights"], dim=0)      # SSeRiouSS.py:309-311
             for i in range(nl):

@@ -117,17 +117,24 @@ def test_kmeans_and_enum_members():
             embeddings=emb, segmentations=SlidingWindowFeature(seg, CHUNKS))
 
 
-def test_unplaced_clustering_object_raises():
-    """no implicit CPU path: a clustering object that was never moved to a device refuses to compute
-    (the SciPy route needs the explicit `.to(torch.device("cpu"))` used throughout this file)."""
+def test_unplaced_clustering_object_is_the_reference_stand_alone_use():
+    """the reference's public API allows `AgglomerativeClustering().instantiate(...)(embeddings, ...)` without any
+    placement (pipelines/clustering.py:214-289): an unplaced object computes on the host through SciPy, exactly like
+    one that was explicitly put there (the PIPELINE itself refuses to run anywhere but on a GPU:
+    tests/test_pipeline_cpu.py)."""
     rng = np.random.default_rng(0)
-    emb = rng.standard_normal((30, 3, 16)).astype(np.float32)
+    centers = rng.standard_normal((2, 16))
+    emb = (centers[rng.integers(0, 2, (30, 3))] + 0.1 * rng.standard_normal((30, 3, 16))).astype(np.float32)
     seg = SlidingWindowFeature(np.ones((30, 589, 3), dtype=np.float32), SlidingWindow(start=0.0, duration=10.0, step=1.0))
     seg.data[:, :, 1:] = 0
-    clu = pa.AgglomerativeClustering(metric="cosine").instantiate(
-        {"method": "centroid", "min_cluster_size": 2, "threshold": 0.7})
-    with pytest.raises(RuntimeError, match="no device set"):
-        clu(embeddings=emb, segmentations=seg, min_clusters=1, max_clusters=np.inf)
+    params = {"method": "centroid", "min_cluster_size": 2, "threshold": 0.7}
+    unplaced = pa.AgglomerativeClustering(metric="cosine").instantiate(params)
+    assert unplaced.device is None
+    on_host = pa.AgglomerativeClustering(metric="cosine").instantiate(params).to(torch.device("cpu"))
+    a = unplaced(embeddings=emb.copy(), segmentations=seg, min_clusters=1, max_clusters=np.inf)
+    b = on_host(embeddings=emb.copy(), segmentations=seg, min_clusters=1, max_clusters=np.inf)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v, equal_nan=True)
 
 
 def test_merge_placement_hint_is_thread_local_and_nests():

@@ -381,3 +381,27 @@ def test_sseriouss_pack_layouts(config, layer):
         got = _emulate_sser_encoder(pack, wav)
     assert got.shape == want.shape
     assert torch.allclose(got, want, rtol=1e-4, atol=2e-5), (got - want).abs().max()
+
+
+def test_sseriouss_wav2vec_forms_of_the_reference(tmp_path):
+    """`wav2vec` hyper-parameter forms of the reference (models/segmentation/SSeRiouSS.py:97-123): a bundle name, the
+    PATH of a self-supervised checkpoint {"config", "state_dict"}, a wav2vec2_model kwargs dict; and
+    `wav2vec_layer=0`, for which torchaudio's extract_features(num_layers=0) raises ValueError."""
+    import oracle.models as om
+    from pyannote_audio_amd.weights import SSeRiouSSPack, wav2vec_config
+    cfg = dict(om.TINY_WAV2VEC2)
+    path = tmp_path / "ssl.ckpt"
+    torch.save({"config": cfg, "state_dict": {}}, path)
+    from_path, from_dict = wav2vec_config(str(path)), wav2vec_config(cfg)
+    assert from_path == from_dict and from_path["wavlm"] is False
+    assert wav2vec_config("WAVLM_BASE")["wavlm"] is True
+    with pytest.raises(NotImplementedError, match="neither one of the built torchaudio bundles"):
+        wav2vec_config("NOT_A_BUNDLE_NOR_A_FILE")
+    torch.save({"state_dict": {}}, path)
+    with pytest.raises(ValueError, match="no 'config' entry"):
+        wav2vec_config(str(path))
+    model = om.seeded_sseriouss(wav2vec=cfg, num_layers=1, wav2vec_layer=1)
+    for layer in (0, cfg["encoder_num_layers"] + 1):
+        with pytest.raises(ValueError, match="`num_layers` must be between"):
+            SSeRiouSSPack(model.state_dict(), {"wav2vec": cfg, "wav2vec_layer": layer, "lstm": {"num_layers": 1}},
+                          7, 3, 2, torch.device("cpu"))

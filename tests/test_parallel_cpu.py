@@ -44,15 +44,40 @@ def _worker(rank, world, port, total, q):
     first = sum(len(per) for per in lens[:rank])
     mine = files[first:first + len(lens[rank])]
     recs = [parallel.pack_records(torch.from_numpy(sg), torch.from_numpy(em)) for sg, em in mine]
-    everything = parallel.all_gather_files(recs, shard, torch.device("cpu"))
-    k = 0
-    for r, per in enumerate(everything):
-        assert len(per) == len(lens[r])
-        for rec in per:
-            sg, em = parallel.unpack_records(rec, 37, 3, 16)
-            ok = ok and np.array_equal(sg.numpy(), files[k][0].astype(np.uint8)) \
-                and np.array_equal(em.numpy(), files[k][1])
-            k += 1
+    def check(everything, lens, files):
+        good, k = True, 0
+        for r, per in enumerate(everything):
+            assert len(per) == len(lens[r])
+            for rec in per:
+                sg, em = parallel.unpack_records(rec, 37, 3, 16)
+                good = good and np.array_equal(sg.numpy(), files[k][0].astype(np.uint8)) \
+                    and np.array_equal(em.numpy(), files[k][1])
+                k += 1
+        return good
+
+    # first exchange of the process group: no agreed capacity yet -> header round + data round
+    before = parallel.collectives_issued
+    ok = ok and check(parallel.all_gather_files(recs, shard, torch.device("cpu")), lens, files)
+    assert parallel.collectives_issued - before == 2
+    # steady state: ONE all-gather (the chunk counts travel in the header of the same buffer)
+    before = parallel.collectives_issued
+    ok = ok and check(parallel.all_gather_files(recs, shard, torch.device("cpu")), lens, files)
+    assert parallel.collectives_issued - before == 1
+    # a rank without files (record size given), still one
+    before = parallel.collectives_issued
+    got = parallel.all_gather_files(recs if rank == 0 else [], shard, torch.device("cpu"), record_bytes=37 * 3 + 4 * 3 * 16)
+    assert parallel.collectives_issued - before == 1 and len(got[1]) == 0 and len(got[0]) == 2
+    # one rank outgrows the agreed capacity (512 chunks): every rank sees the overflow flag and repeats once
+    big = (rng.uniform(size=(700, 37, 3)) < 0.4, rng.standard_normal((700, 3, 16)).astype(np.float32))
+    lens2, files2 = [[5, 2], [700]], files[:2] + [big]
+    mine2 = files2[:2] if rank == 0 else [big]
+    recs2 = [parallel.pack_records(torch.from_numpy(sg), torch.from_numpy(em)) for sg, em in mine2]
+    before = parallel.collectives_issued
+    ok = ok and check(parallel.all_gather_files(recs2, shard, torch.device("cpu")), lens2, files2)
+    assert parallel.collectives_issued - before == 2
+    before = parallel.collectives_issued
+    ok = ok and check(parallel.all_gather_files(recs2, shard, torch.device("cpu")), lens2, files2)
+    assert parallel.collectives_issued - before == 1
     q.put((rank, b, e, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

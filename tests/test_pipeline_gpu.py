@@ -194,6 +194,31 @@ def test_linkage_late_tie_falls_back_to_the_heap(gpu_device, wgs, monkeypatch):
     assert st[8] == 1 and st[15] == 72 and st[7] == len(X)   # gave up at merge 72, like the model; the heap ran
 
 
+@pytest.mark.parametrize("n,d,k,seed", [(1, 256, 1, 0), (40, 256, 1, 1), (500, 256, 7, 2), (7176, 256, 50, 3),
+                                        (3000, 300, 13, 4), (9, 16, 20, 5)])
+def test_centroid_means_bit_exact(gpu_device, n, d, k, seed):
+    """pa_centroid_means (north_star: "centroid updates ... run as a HIP kernel"; reference pipelines/clustering.py:
+    182-187) == the reference's np.mean(X[labels == c], axis=0) per cluster, bit for bit, on rows selected out of a
+    larger device-resident embedding matrix; empty clusters give NaN rows like the host restatement."""
+    from pyannote_audio_amd import distance
+    from pyannote_audio_amd.clustering import segment_means
+    rng = np.random.default_rng(seed)
+    total = 3 * n + 5
+    X = (rng.standard_normal((total, d)) * rng.uniform(0.1, 30.0, (total, 1))).astype(np.float32)
+    rows = np.sort(rng.choice(total, n, replace=False))
+    labels = rng.integers(0, k, n)
+    if k > 3:
+        labels[labels == 2] = 1            # an empty cluster in the middle
+    got = distance.centroid_means(torch.from_numpy(X).to(gpu_device), rows, labels, k, gpu_device)
+    want = segment_means(X[rows], labels, k)
+    for c in range(k):
+        sel = X[rows][labels == c]
+        if len(sel):
+            assert np.array_equal(want[c], np.mean(sel, axis=0))      # the host restatement IS the reference call
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_non_powerset_pipeline_matches_oracle(synthetic_models, gpu_device, tmp_path):
     """a14: a multi-label segmentation checkpoint -- sigmoid scores out of the
     classifier kernel, hysteresis thresholding (pipelines/speaker_diarization.py:599-606, utils/signal.py:
