@@ -191,6 +191,15 @@ int pa_winograd_pack_host(const float* conv_weight /* (cout, cin, 3, 3), resnet.
                           float* U_slabs /* HOST buffer, 16 * cout * cin floats */);
 int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                     const float* R, float* Y, int cout, int relu, void* stream);
+/* the same stride-1 convolution through Winograd F(4x4,3x3) (csrc/emb_winograd4.hip: 36 instead of 64 multiplies per
+ * 16 outputs; error ~1e-5 of max |Y| per convolution, tools/probes/winograd_f4_numerics.py).  U: G g G^T packed as
+ * one contiguous 36-KB slab per (32-cout slice, 8-cin stage), [cout/32][cin/8][row = 32 xi + (cout % 32)][8] with
+ * xi = 6a + b -- build it with pa_winograd4_pack_host (cout % 32 == 0, cin % 8 == 0, cin >= 32). */
+int pa_winograd4_pack_host(const float* conv_weight /* (cout, cin, 3, 3), resnet.py:92-107 */,
+                           const float* bn_scale /* (cout) gamma / sqrt(var + eps), or NULL */, int cout, int cin,
+                           float* U_slabs /* HOST buffer, 36 * cout * cin floats */);
+int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                     const float* R, float* Y, int cout, int relu, void* stream);
 int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream);
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream);

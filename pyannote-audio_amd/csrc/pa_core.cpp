@@ -176,3 +176,41 @@ extern "C" int pa_winograd_pack_host(const float* conv_weight, const float* bn_s
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// HOST helper: the weight image pa_conv3x3_wino4 expects.  U = G g G^T of Winograd F(4x4,3x3) in float64 arithmetic
+// (BatchNorm scale folded per output channel in float32 first, as weights.py does), packed as one contiguous 36-KB
+// slab per (32-cout slice, 8-cin stage): [cout/32][cin/8][row = 32 xi + n][8], xi = 6a + b, n = cout % 32.
+// Same result as weights.winograd4_pack(winograd4_weights(w * scale)).
+// ---------------------------------------------------------------------------------------------
+extern "C" int pa_winograd4_pack_host(const float* conv_weight, const float* bn_scale, int cout, int cin,
+                                      float* U_slabs) {
+  if (cout <= 0 || cin <= 0 || cout % 32 != 0 || cin % 8 != 0 || !conv_weight || !U_slabs) {
+    pa::set_error("pa_winograd4_pack_host: cout %% 32 == 0 and cin %% 8 == 0 required (got %d, %d)", cout, cin);
+    return 3;
+  }
+  static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1.0}};
+  const int stages = cin / 8;
+  for (int o = 0; o < cout; ++o)
+    for (int i = 0; i < cin; ++i) {
+      double g[3][3];
+      for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+          const float folded = bn_scale ? conv_weight[((size_t)o * cin + i) * 9 + p * 3 + q] * bn_scale[o]
+                                        : conv_weight[((size_t)o * cin + i) * 9 + p * 3 + q];
+          g[p][q] = (double)folded;
+        }
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          // the same contraction order as torch.einsum("ap,oipq,bq->aboi") is NOT needed bit for bit by the kernel,
+          // but the Python pack is the test's reference: sum over (p, q) in row-major order of exact products
+          double u = 0.0;
+          for (int p = 0; p < 3; ++p)
+            for (int q = 0; q < 3; ++q) u += G[a][p] * g[p][q] * G[b][q];
+          const size_t slab = ((size_t)(o / 32) * stages + i / 8) * 36 * 32 * 8;
+          U_slabs[slab + (size_t)(32 * (6 * a + b) + (o % 32)) * 8 + (i % 8)] = (float)u;
+        }
+    }
+  return 0;
+}

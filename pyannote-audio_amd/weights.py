@@ -485,6 +485,29 @@ def winograd_pack(U: torch.Tensor) -> torch.Tensor:
     return torch.gather(A, 3, idx).contiguous()
 
 
+#: G of Winograd F(4x4, 3x3) (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf)
+WINOGRAD4_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+               [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
+
+
+def winograd4_weights(cw: torch.Tensor) -> torch.Tensor:
+    """(cout, cin, 3, 3) -> [36][cout][cin] float32: U = G g G^T of Winograd F(4x4, 3x3), computed in float64
+    (xi = 6a + b indexes the 6x6 transform domain)."""
+    G = torch.tensor(WINOGRAD4_G, dtype=torch.float64)
+    U = torch.einsum("ap,oipq,bq->aboi", G, cw.double(), G)
+    return U.reshape(36, cw.shape[0], cw.shape[1]).float().contiguous()
+
+
+def winograd4_pack(U: torch.Tensor) -> torch.Tensor:
+    """[36][cout][cin] -> the staging image of csrc/emb_winograd4.hip, [cout/32][cin/8][row = 32 xi + n][8]: one
+    CONTIGUOUS 36-KB slab per (32-cout slice, 8-cin stage), so that its LDS-DMA is a linear stream and lane
+    (n & 15, g) of the MFMA's A operand reads the input-channel pair g of output channel n at byte 32 row + 8 g."""
+    _, cout, cin = U.shape
+    assert cout % 32 == 0 and cin % 8 == 0
+    A = U.reshape(36, cout // 32, 32, cin // 8, 8).permute(1, 3, 0, 2, 4)
+    return A.reshape(cout // 32, cin // 8, 36 * 32, 8).contiguous()
+
+
 def _fold_bn(sd: dict, prefix: str, eps: float = 1e-5):
     scale = sd[prefix + ".weight"] / torch.sqrt(sd[prefix + ".running_var"] + eps)
     shift = sd[prefix + ".bias"] - sd[prefix + ".running_mean"] * scale

@@ -187,6 +187,44 @@ def test_conv3x3_winograd(gpu_device):
         assert north_star_ratio(f"wino3x3_{cin}_{cout}_{H}x{W}_B{B}", y.permute(0, 3, 1, 2), ref) <= 1.0
 
 
+def test_conv3x3_winograd_f4(gpu_device):
+    """pa_conv3x3_wino4 (Winograd F(4x4,3x3), fp32) vs torch conv2d: all ResNet34 channel configurations, odd /
+    ragged extents (tiles, tile rows and whole waves outside the image), with and without residual, enough images
+    for several tiles per workgroup.  Bound per convolution: |err| <= 1e-4 max |ref| (F(4x4)'s transforms cost a
+    digit against F(2x2): 2-6e-5 of the maximum on unit-variance data, tools/probes/winograd_f4_numerics.py; the
+    element-wise north-star bound is asserted on the EMBEDDINGS, test_emb_forward_* / test_golden.py)."""
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.weights import winograd4_pack, winograd4_weights
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(12)
+    cases = [(32, 32, 80, 70, 2, True), (64, 64, 40, 45, 2, True), (128, 128, 20, 37, 2, False),
+             (256, 256, 10, 71, 2, True), (32, 32, 17, 9, 3, True), (64, 64, 1, 1, 2, False),
+             (32, 32, 80, 270, 24, True), (256, 256, 10, 125, 40, False), (128, 128, 20, 250, 20, True),
+             (40, 32, 9, 129, 3, False)]
+    for cin, cout, H, W, B, use_res in cases:
+        x = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+        sh = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, W, generator=g)
+        ref = F.conv2d(x, wt, stride=1, padding=1) + sh.view(1, -1, 1, 1)
+        ref = F.relu(ref + res if use_res else ref)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        ud = winograd4_pack(winograd4_weights(wt)).to(gpu_device)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        shd = sh.to(gpu_device)
+        y = torch.full((B, H, W, cout), float("nan"), device=gpu_device)
+        ffi.check(lib.pa_conv3x3_wino4(ffi.ptr(xd), B, H, W, cin, ffi.ptr(ud), ffi.ptr(shd),
+                                       ffi.ptr(rd) if use_res else None, ffi.ptr(y), cout, 1, ffi.stream()),
+                  "conv3x3_wino4")
+        torch.cuda.synchronize()
+        got = y.permute(0, 3, 1, 2).cpu()
+        assert not torch.isnan(got).any(), (cin, cout, H, W, B)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        elementwise = north_star_ratio(f"wino4_3x3_{cin}_{cout}_{H}x{W}_B{B}", got, ref)   # logged, not the bound here
+        print(f"wino4 {cin}->{cout} {H}x{W} B{B}: max |err| / max |ref| = {err:.2e} (element-wise ratio {elementwise:.2f})")
+        assert err <= 1e-4, (cin, cout, H, W, B, err)
+
+
 @pytest.mark.parametrize("num_blocks", [(1, 1, 1, 1), (2, 3, 2, 2)])
 def test_bottleneck_resnet_matches_oracle(gpu_device, num_blocks):
     """WeSpeakerResNet152/221/293 (wespeaker/resnet.py:148-212, 477-507): Bottleneck

@@ -24,3 +24,18 @@ def test_dma_layout_matches_transform_reads_and_is_conflict_free(tmp_path):
                            str(ROOT / "tests" / "native" / "winograd_geom_harness.cpp"), "-o", str(exe)])
     rc = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert rc.returncode == 0, rc.stdout + rc.stderr
+
+
+def test_f4_dma_layout_matches_transform_reads(tmp_path):
+    """csrc/emb_winograd4_geom.h (Winograd F(4x4, 3x3), k_conv3x3_wino4): patch DMA vs the 6x6 transform reads of
+    every wave and lane, zeros for EVERY pixel outside the image, contiguous 512-byte ds_read_b64s, U-slab reads
+    (tests/native/winograd4_geom_harness.cpp)."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("g++ not available")
+    exe = tmp_path / "geom4"
+    subprocess.check_call([gxx, "-O2", "-std=c++17", "-Wno-unknown-pragmas",
+                           "-I", str(ROOT / "pyannote-audio_amd" / "csrc"),
+                           str(ROOT / "tests" / "native" / "winograd4_geom_harness.cpp"), "-o", str(exe)])
+    rc = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert rc.returncode == 0, rc.stdout + rc.stderr

@@ -1,5 +1,5 @@
 """Per-shape timing of pa_conv3x3 on the ResNet34 layer shapes (development aid; HIP events through
-the library profiler).  usage: [WINO=1] [ONLY_S1=1] [PA_LIB=variant.so] python tools/bench_conv.py [B] [reps]"""
+the library profiler).  usage: [WINO=1|4] [ONLY_S1=1] [PA_LIB=variant.so] python tools/bench_conv.py [B] [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,10 +23,17 @@ for (H, W, ci, co, s, res) in shapes:
     sh = torch.randn(co, device=dev)
     R = torch.randn(B, Ho, Wo, co, device=dev) if res else None
     Y = torch.empty(B, Ho, Wo, co, device=dev)
-    from pyannote_audio_amd.weights import winograd_pack, winograd_weights
+    from pyannote_audio_amd.weights import winograd_pack, winograd_weights, winograd4_pack, winograd4_weights
     wino = os.environ.get("WINO", "0") == "1" and s == 1
+    wino4 = os.environ.get("WINO", "0") == "4" and s == 1          # Winograd F(4x4,3x3), csrc/emb_winograd4.hip
     Ug = winograd_pack(winograd_weights(Wg.permute(1, 2, 0).reshape(co, ci, 3, 3).cpu())).to(dev) if wino else None
+    if wino4:
+        Ug = winograd4_pack(winograd4_weights(Wg.permute(1, 2, 0).reshape(co, ci, 3, 3).cpu())).to(dev)
     def run():
+        if wino4:
+            ffi.check(lib.pa_conv3x3_wino4(ffi.ptr(X), B, H, W, ci, ffi.ptr(Ug), ffi.ptr(sh), ffi.ptr(R), ffi.ptr(Y),
+                                           co, 1, ffi.stream()), "wino4")
+            return
         if wino:
             ffi.check(lib.pa_conv3x3_wino(ffi.ptr(X), B, H, W, ci, ffi.ptr(Ug), ffi.ptr(sh), ffi.ptr(R), ffi.ptr(Y),
                                           co, 1, ffi.stream()), "wino")
@@ -39,7 +46,7 @@ for (H, W, ci, co, s, res) in shapes:
     for _ in range(reps): run()
     torch.cuda.synchronize()
     rep = ffi.prof_report()
-    r = rep.get("k_conv3x3_wino") or rep["k_conv3x3"]
+    r = rep.get("k_conv3x3_wino4") or rep.get("k_conv3x3_wino") or rep["k_conv3x3"]
     ffi.prof_enable(False)
     ms = r["ms"] / r["launches"]
     print(f"conv {H}x{W} {ci}->{co} s{s} res={int(res)}: {ms:.3f} ms  {r['flops']/r['ms']/1e9:.1f} TFLOP/s "
