@@ -41,9 +41,11 @@ import torch.distributed as dist
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 # kernels whose roofline is the f32 MFMA rate; everything else is priced against HBM bandwidth
-MFMA_KERNELS = {"k_conv3x3", "k_conv3x3_wino", "k_gemm_tn", "k_lstm_rec", "k_sinc_fir_pool", "k_conv5_pool"}
-# Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and (cin, cout) pair instead of 36
-EXECUTED_FLOP_FRACTION = {"k_conv3x3_wino": 16.0 / 36.0}
+MFMA_KERNELS = {"k_conv3x3", "k_conv3x3_wino", "k_conv3x3_wino4", "k_gemm_tn", "k_lstm_rec", "k_sinc_fir_pool",
+                "k_conv5_pool", "k_sinc_fir_span"}
+# Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and (cin, cout) pair instead of 36; F(4x4,3x3) 36
+# per 4x4 tile instead of 144
+EXECUTED_FLOP_FRACTION = {"k_conv3x3_wino": 16.0 / 36.0, "k_conv3x3_wino4": 36.0 / 144.0}
 # bare v_mfma_f32_16x16x4_f32 stream measured on MI355X with random operands over 0.7 s: 151.8 TFLOP/s at
 # a 2.37 GHz shader clock (profiles/r2_clock_trace.txt; bursts of a few ms run at ~2.1 GHz while the
 # clock ramps: profiles/r2_mfma_probe_box2.txt)

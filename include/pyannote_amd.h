@@ -160,6 +160,10 @@ typedef struct pa_emb_weights {
   const float* blk_shift3[PA_MAX_RES_BLOCKS];
   const float* seg1_w; /* [embed_dim][2 * expansion * planes[3] * num_mel/8] */
   const float* seg1_b;
+  /* Winograd F(4x4,3x3) images of w1 / w2 (pa_winograd4_pack_host), or NULL: when set, a stride-1 3x3 convolution
+   * runs through pa_conv3x3_wino4 instead of pa_conv3x3_wino (blk_u*) / pa_conv3x3 (blk_w*) */
+  const float* blk_v1[PA_MAX_RES_BLOCKS];
+  const float* blk_v2[PA_MAX_RES_BLOCKS];
 } pa_emb_weights;
 
 /* fbank frames for num_samples (25 ms / 10 ms, snip_edges) and frames after the 3 stride-2 stages */

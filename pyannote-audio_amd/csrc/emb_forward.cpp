@@ -195,7 +195,10 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         RUN(pa_gather_s2(cur, B, H, W, cin, G, stream));
         RUN(pa_gemm_tn(G, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, B * Ho * Wo, cout, cin,
                        0, 0, stream));
-        if (w->blk_u2[blk] != nullptr)
+        if (w->blk_v2[blk] != nullptr)
+          RUN(pa_conv3x3_wino4(f1, B, Ho, Wo, cout, w->blk_v2[blk], w->blk_shift2[blk], R, cur, cout, 1,
+                               stream));
+        else if (w->blk_u2[blk] != nullptr)
           RUN(pa_conv3x3_wino(f1, B, Ho, Wo, cout, w->blk_u2[blk], w->blk_shift2[blk], R, cur, cout, 1,
                               stream));
         else
@@ -206,13 +209,19 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
           pa::set_error("pa_emb_forward: block %d needs a shortcut conv but none was given", blk);
           return 3;
         }
-        if (w->blk_u1[blk] != nullptr)
+        if (w->blk_v1[blk] != nullptr)
+          RUN(pa_conv3x3_wino4(cur, B, H, W, cin, w->blk_v1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1,
+                               stream));
+        else if (w->blk_u1[blk] != nullptr)
           RUN(pa_conv3x3_wino(cur, B, H, W, cin, w->blk_u1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1,
                               stream));
         else
           RUN(pa_conv3x3(cur, B, H, W, cin, w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1, 1,
                          stream));
-        if (w->blk_u2[blk] != nullptr)
+        if (w->blk_v2[blk] != nullptr)
+          RUN(pa_conv3x3_wino4(f1, B, H, W, cout, w->blk_v2[blk], w->blk_shift2[blk], cur, f2, cout, 1,
+                               stream));
+        else if (w->blk_u2[blk] != nullptr)
           RUN(pa_conv3x3_wino(f1, B, H, W, cout, w->blk_u2[blk], w->blk_shift2[blk], cur, f2, cout, 1,
                               stream));
         else

@@ -42,6 +42,27 @@
 
 namespace pa {
 
+#ifndef PA_W4_STAMP
+#define PA_W4_STAMP 0
+#endif
+#if PA_W4_STAMP
+// development instrumentation (never in the product build): s_memtime at the phases of the first 64 stages of
+// workgroups 0 .. 7, per wave; read back with pa_wino4_read_stamps
+__device__ unsigned long long g_w4_stamps[8 * 4 * 64 * 6];
+#define W4_STAMP(p) st_[p] = __builtin_amdgcn_s_memtime()
+#define W4_STAMP_FLUSH()                                                                      \
+  do {                                                                                        \
+    if (blockIdx.x < 8 && st_iter < 64 && lane == 0) {                                         \
+      _Pragma("unroll") for (int p_ = 0; p_ < 6; ++p_)                                         \
+          g_w4_stamps[((blockIdx.x * 4 + slw) * 64 + st_iter) * 6 + p_] = st_[p_];             \
+    }                                                                                         \
+    ++st_iter;                                                                                \
+  } while (0)
+#else
+#define W4_STAMP(p)
+#define W4_STAMP_FLUSH()
+#endif
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds4_ptr_t;
 
@@ -75,7 +96,7 @@ __device__ __forceinline__ void wino4_bt(const f32x2 (&x)[6], f32x2 (&y)[6], con
 //   y0 = m0 + (m1 + m2) + (m3 + m4)     y1 = (m1 - m2) + 2 (m3 - m4)
 //   y2 = (m1 + m2) + 4 (m3 + m4)        y3 = (m1 - m2) + 8 (m3 - m4) + m5
 struct W4Const4 {
-  f32x4 m1, p2, p4, p8;
+  f32x4 m1, p2, p4, p8, m2, m8;
 };
 __device__ __forceinline__ f32x4 w4fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ void wino4_at(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3,
@@ -88,42 +109,79 @@ __device__ __forceinline__ void wino4_at(const f32x4 m0, const f32x4 m1, const f
 }
 
 // v_mfma_f32_16x16x4_f32 with the accumulator pinned to a register class ("a": AccVGPRs, "v": architectural)
-constexpr int W4_AGPR_POINTS = 32;
+constexpr int W4_AGPR_POINTS = 32;   // 256 AccVGPRs; 4 points (32 registers) stay architectural
 #define W4_MFMA_A(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define W4_MFMA_A_ZERO(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
 #define W4_MFMA_V(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define W4_MFMA_V_ZERO(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
 
-// opaque constants (kept in registers: a literal would be folded into unpacked single-lane arithmetic)
+// opaque constants in SCALAR registers (a literal would be folded into unpacked single-lane arithmetic, a vector
+// register per constant is what made the epilogue spill: 28 registers of splats)
 __device__ __forceinline__ float w4_opaque(float v) {
-  asm volatile("" : "+v"(v));
+  asm volatile("" : "+s"(v));
   return v;
 }
 
-__device__ __forceinline__ void wino4_issue(const float* __restrict__ X, int H, int W, int CIN,
-                                            const float* __restrict__ U, int COUT, const WinoTile& q, int c0,
-                                            unsigned char* buf, const int* prel, int lane, int slw, int x0_last) {
+// One stage's staging = 20 LDS-DMA pieces of 1 KB per wave (11 of the patch, 9 of the U slab).  A wave's DMA
+// instruction costs it 150-200 cycles of issue on its own (tools/probes/dma_probe.py) but 5-25 inside its own MFMA
+// run (interleave_probe.py) -- and with one wave per SIMD nobody else fills those cycles (first build of this kernel:
+// all 20 in front of the transform, 14.8 k cycles per stage instead of the 6.5 k its instructions add up to,
+// profiles/r4_wino4_v1_dma_exposed.txt).  So the pieces of stage s + 1 are issued from INSIDE the MFMA run of stage
+// s, two behind each of its first ten point pairs; the rest of the run hides their flight.
+struct Wino4Stage {       // wave-uniform
+  __amdgpu_buffer_rsrc_t xsrd, usrd;
+  int keep, usoff;
+  unsigned char* buf;
+};
+__device__ __forceinline__ Wino4Stage wino4_stage(const float* __restrict__ X, int H, int W, int CIN,
+                                                  const float* __restrict__ U, int COUT, const WinoTile& q, int c0,
+                                                  unsigned char* buf, int x0_last) {
   using G = Wino4Geom;
   const long img = (long)H * W * CIN;
   const long org = ((long)(q.y0 - 1) * W + (q.x0 - 1)) * CIN + c0;
-  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(X + (long)q.b * img + org), 0, (int)((img - org) * 4), 0x00020000);
-  const int keep = wino_patch_keep(q, x0_last);
-#pragma unroll
-  for (int i = 0; i < G::NPP; ++i) {
-    const int k = slw + 4 * i;
-    if (k >= G::PINSTR) break;   // wave-uniform
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds4_ptr_t)(buf + 1024 * k), 16, prel[i] & keep, 0, 0, 0);
+  Wino4Stage st;
+  st.xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (long)q.b * img + org), 0,
+                                              (int)((img - org) * 4), 0x00020000);
+  st.usrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 36 * COUT * CIN * 4, 0x00020000);
+  st.keep = wino_patch_keep(q, x0_last);
+  st.usoff = ((q.n0 / W_BN) * (CIN / G::CB) + c0 / G::CB) * G::USLAB_BYTES;
+#ifdef PA_W4_NOPATCH   // development A/B (never in the product build): every patch lane out of bounds -> no traffic
+  st.keep = -1;
+#endif
+#ifdef PA_W4_NOU       // ... every U piece from slab 0 (L2-resident)
+  st.usoff = 0;
+#endif
+  st.buf = buf;
+  return st;
+}
+constexpr int W4_PIECES = Wino4Geom::NPP + 9;
+struct Wino4Lanes {       // per-lane patch offsets + class bits (wino4_patch_lanes), one per piece of this wave
+  int a[Wino4Geom::NPP];
+};
+// (I is a compile-time constant at every call site after unrolling)
+__device__ __forceinline__ void wino4_piece(const int I, const Wino4Stage& st, const Wino4Lanes& pl, int lane,
+                                            int slw) {
+  using G = Wino4Geom;
+  if (I < G::NPP) {
+    const int k = slw + 4 * I;
+    const int* prel = pl.a;
+    if (k < G::PINSTR)   // wave-uniform
+#ifdef PA_W4_NOPATCH
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.buf + 1024 * k), 16, prel[I] | WCLS_PAD, 0, 0,
+                                               0);
+#else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.buf + 1024 * k), 16, prel[I] & st.keep, 0, 0,
+                                               0);
+#endif
+  } else {
+    const int k = slw + 4 * (I - G::NPP);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.usrd, (lds4_ptr_t)(st.buf + G::PATCH_BYTES + 1024 * k), 16, lane * 16,
+                                             st.usoff + 1024 * k, 0, 0);
   }
-  const __amdgpu_buffer_rsrc_t usrd = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(U), 0, 36 * COUT * CIN * 4, 0x00020000);
-  const int slab = (q.n0 / W_BN) * (CIN / G::CB) + c0 / G::CB;
+}
+__device__ __forceinline__ void wino4_issue_all(const Wino4Stage& st, const Wino4Lanes& pl, int lane, int slw) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int k = slw + 4 * i;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(usrd, (lds4_ptr_t)(buf + G::PATCH_BYTES + 1024 * k), 16, lane * 16,
-                                             slab * G::USLAB_BYTES + 1024 * k, 0, 0);
-  }
+  for (int i = 0; i < W4_PIECES; ++i) wino4_piece(i, st, pl, lane, slw);
 }
 
 template <bool HAS_R>
@@ -148,8 +206,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     return;
   }
   const int x0_last = (tiles_w - 1) * G::TW;
-  int prel[G::NPP];
-  wino4_patch_lanes(prel, W, CIN, lane, slw, x0_last);
+  Wino4Lanes pl;
+  wino4_patch_lanes(pl.a, W, CIN, lane, slw, x0_last);
   const int pbase = wino4_patch_base(t, g, wr, wc);
   const int ubase = wino4_u_base(t, g);
   W4Const kc;
@@ -163,27 +221,36 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 
   WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, G::TH, G::TW, num_pb), nxt = cur;
   int buf = 0;
-  wino4_issue(X, H, W, CIN, U, COUT, cur, 0, smem4, prel, lane, slw, x0_last);
+  wino4_issue_all(wino4_stage(X, H, W, CIN, U, COUT, cur, 0, smem4, x0_last), pl, lane, slw);
   int claim = 0;
   if (tid == 0) claim = tq_claim_own(tq);
   int nq = -1;
   f32x4 acca[W4_AGPR_POINTS][2];        // points 0 .. 31: AccVGPRs
   f32x4 accv[36 - W4_AGPR_POINTS][2];   // points 32 .. 35: architectural registers
 
+#if PA_W4_STAMP
+  unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+  int st_iter = 0;
+#endif
   while (true) {
     for (int s = 0; s < nstages; ++s) {
+      W4_STAMP(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
+      W4_STAMP(1);
       wino4_barrier();                                    // ... everybody's; and everybody is done with the other buffer
+      W4_STAMP(2);
       unsigned char* mine = smem4 + buf * G::BUF_BYTES;
       unsigned char* other = smem4 + (buf ^ 1) * G::BUF_BYTES;
+      // what the MFMA run below stages: the next stage of this tile, or the first stage of the next one
+      bool stage_next = true;
+      Wino4Stage nst;
       if (s + 1 < nstages) {
-        wino4_issue(X, H, W, CIN, U, COUT, cur, (s + 1) * G::CB, other, prel, lane, slw, x0_last);
+        nst = wino4_stage(X, H, W, CIN, U, COUT, cur, (s + 1) * G::CB, other, x0_last);
       } else {
         nq = mail[0];   // (written by thread 0 in front of this stage's barrier)
-        if (nq >= 0) {
-          nxt = wino_decode(nq, tiles_w, tiles_hw, n_tiles, G::TH, G::TW, num_pb);
-          wino4_issue(X, H, W, CIN, U, COUT, nxt, 0, other, prel, lane, slw, x0_last);
-        }
+        stage_next = nq >= 0;
+        nxt = wino_decode(stage_next ? nq : 0, tiles_w, tiles_hw, n_tiles, G::TH, G::TW, num_pb);
+        nst = wino4_stage(X, H, W, CIN, U, COUT, nxt, 0, other, x0_last);
       }
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
@@ -214,6 +281,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#if PA_W4_STAMP
+      asm volatile("s_nop 0" ::"v"(v[5][5]), "v"(v[0][0]));   // the transform is complete here
+#endif
+      W4_STAMP(3);
       // ---- 36 points x 2 channel groups x 2 k-steps, two points at a time (a dependent MFMA is four MFMAs behind
       // its producer); U fragments of the next pair are read while this pair's MFMAs issue.  The MFMAs are inline
       // assembly because the accumulators must be PINNED: 32 points in the 256 AccVGPRs, 4 in architectural
@@ -230,47 +301,69 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
         for (int xp = 0; xp < 36; xp += 2) {
           const int par = (xp >> 1) & 1;
-          if (xp + 2 < 36) {
+          // eight MFMAs per point pair, everything else spread between them one instruction at a time (an LDS read
+          // or an LDS-DMA issued right behind an MFMA costs the wave nothing while that MFMA executes; two DMA
+          // pieces back to back do: first build of this loop, 6 240 cycles per run instead of 4 608 + ~600)
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+          for (int m = 0; m < 8; ++m) {
+            const int ks = m >> 2, e = (m >> 1) & 1, cg = m & 1;
+            const int xi = xp + e;
+            const f32x2 bv = v[xi / 6][xi % 6];
+            const float a = ks ? uf[par][e][cg].y : uf[par][e][cg].x, b = ks ? bv.y : bv.x;
+            if (xi < W4_AGPR_POINTS) {
+              if (ks == 0 && FIRST) W4_MFMA_A_ZERO(acca[xi < W4_AGPR_POINTS ? xi : 0][cg], a, b);
+              else W4_MFMA_A(acca[xi < W4_AGPR_POINTS ? xi : 0][cg], a, b);
+            } else {
+              if (ks == 0 && FIRST) W4_MFMA_V_ZERO(accv[xi >= W4_AGPR_POINTS ? xi - W4_AGPR_POINTS : 0][cg], a, b);
+              else W4_MFMA_V(accv[xi >= W4_AGPR_POINTS ? xi - W4_AGPR_POINTS : 0][cg], a, b);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef PA_W4_NOUREAD   // (development A/B: the same fragments for every point -> what the U reads cost)
+            if ((m == 0 || m == 2) && xp + 2 < 36) {      // U fragments of the next pair, one point per slot
+              const int en = m >> 1;
 #pragma unroll
-              for (int cg = 0; cg < 2; ++cg)
-                uf[par ^ 1][e][cg] = *reinterpret_cast<const f32x2*>(ub + wino4_u_k(xp + 2 + e, cg));
+              for (int c2 = 0; c2 < 2; ++c2)
+                uf[par ^ 1][en][c2] = *reinterpret_cast<const f32x2*>(ub + wino4_u_k(xp + 2 + en, c2));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#else
+            if (xp == 0 && m == 0) {
+#pragma unroll
+              for (int en = 0; en < 2; ++en)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) uf[1][en][c2] = uf[0][en][c2];
+            }
+#endif
+#ifndef PA_W4_NODMA     // (development A/B: no staging at all from inside the run)
+            if ((m == 4 || m == 6) && stage_next) {       // wave-uniform; pieces xp, xp + 1 of the next stage
+              const int piece = xp + ((m - 4) >> 1);
+              if (piece < W4_PIECES) wino4_piece(piece, nst, pl, lane, slw);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
           }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-              for (int cg = 0; cg < 2; ++cg) {
-                const int xi = xp + e;
-                const f32x2 bv = v[xi / 6][xi % 6];
-                const float a = ks ? uf[par][e][cg].y : uf[par][e][cg].x, b = ks ? bv.y : bv.x;
-                if (xi < W4_AGPR_POINTS) {
-                  if (ks == 0 && FIRST) W4_MFMA_A_ZERO(acca[xi < W4_AGPR_POINTS ? xi : 0][cg], a, b);
-                  else W4_MFMA_A(acca[xi < W4_AGPR_POINTS ? xi : 0][cg], a, b);
-                } else {
-                  if (ks == 0 && FIRST) W4_MFMA_V_ZERO(accv[xi >= W4_AGPR_POINTS ? xi - W4_AGPR_POINTS : 0][cg], a, b);
-                  else W4_MFMA_V(accv[xi >= W4_AGPR_POINTS ? xi - W4_AGPR_POINTS : 0][cg], a, b);
-                }
-              }
-          __builtin_amdgcn_sched_barrier(0);
         }
       };
       if (s == 0) mfma_run(std::true_type{});
       else mfma_run(std::false_type{});
+      W4_STAMP(4);
       if (s == nstages - 2 && tid == 0) mail[0] = tq_resolve(tq, claim);   // published by the next barrier
       buf ^= 1;
+      if (s + 1 < nstages) {
+        W4_STAMP(5);
+        W4_STAMP_FLUSH();
+      }
     }
     // ---- inverse transform A^T M A + BN shift (+ residual) (+ ReLU), 16-byte stores
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (the compiler cannot see them)
     {
       W4Const4 k4;
       {
-        const float m1 = w4_opaque(-1.f), p2 = w4_opaque(2.f), p4 = w4_opaque(4.f), p8 = w4_opaque(8.f);
+        const float m1 = w4_opaque(-1.f), p2 = w4_opaque(2.f), p4 = w4_opaque(4.f), p8 = w4_opaque(8.f),
+                    m2 = w4_opaque(-2.f), m8 = w4_opaque(-8.f);
         k4.m1 = f32x4{m1, m1, m1, m1}; k4.p2 = f32x4{p2, p2, p2, p2};
         k4.p4 = f32x4{p4, p4, p4, p4}; k4.p8 = f32x4{p8, p8, p8, p8};
+        k4.m2 = f32x4{m2, m2, m2, m2}; k4.m8 = f32x4{m8, m8, m8, m8};
       }
       const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
           Y + (long)cur.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
@@ -285,59 +378,102 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       for (int qq = 0; qq < 4; ++qq) offq[qq] = (cur.valid && xl + qq < W) ? obase + qq * spix : OOB;
       const float lo = relu ? 0.f : -__builtin_inff();
       const f32x4 lo4 = {lo, lo, lo, lo};
+      // Every accumulator is read ONCE, column by column of the 6x6 point grid: y = A^T M[:, b] (10 operations),
+      // then its 18 non-zero contributions AT[q][b] y[p] go straight into the 4x4 outputs.  (Two passes over the
+      // accumulators -- rows 0-1, then rows 2-3 -- made the compiler keep every accumulator's VGPR copy alive
+      // between them: 180 registers, 70-100 spills, 17 k cycles per tile.)
+#define W4_ACC(xi) ((xi) < W4_AGPR_POINTS ? acca[(xi) < W4_AGPR_POINTS ? (xi) : 0][cg] \
+                                          : accv[(xi) >= W4_AGPR_POINTS ? (xi)-W4_AGPR_POINTS : 0][cg])
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + cur.n0 + 16 * cg + 4 * g);
+        f32x4 rv[2][4];
+        if (HAS_R) {   // rows 0-1 now (their latency hides under the inverse transform), rows 2-3 behind them
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {     // output rows 2h, 2h + 1 of the tile
-          f32x4 rv[2][4];
-          if (HAS_R) {
+          for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int qq = 0; qq < 4; ++qq)
+              rv[p][qq] = __builtin_bit_cast(
+                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                             rsrd, offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 o[4][4];
 #pragma unroll
-              for (int qq = 0; qq < 4; ++qq)
-                rv[p][qq] = __builtin_bit_cast(
-                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                               rsrd, offq[qq] == OOB ? OOB : offq[qq] + (2 * h + p) * srow + 64 * cg, 0, 0));
+        for (int b = 0; b < 6; ++b) {
+          // (an empty volatile asm re-defines each accumulator of this column HERE: instruction selection otherwise
+          //  emits the AccVGPR -> VGPR copies of all 72 accumulators at the top of the epilogue -- sched_barrier only
+          //  binds the machine scheduler -- and 288 live registers spill)
+#pragma unroll
+          for (int a6 = 0; a6 < 6; ++a6) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int xi = 6 * a6 + b;
+            if (xi < W4_AGPR_POINTS) asm volatile("" : "+a"(acca[xi < W4_AGPR_POINTS ? xi : 0][cg]));
           }
-          __builtin_amdgcn_sched_barrier(0);
-          // rows: z[p][b] = sum_a AT[2h + p][a] M[a][b]
-          f32x4 z[2][6];
+          f32x4 y[4];
+          wino4_at(W4_ACC(0 + b), W4_ACC(6 + b), W4_ACC(12 + b), W4_ACC(18 + b), W4_ACC(24 + b), W4_ACC(30 + b), y,
+                   k4);
 #pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            const f32x4 m0 = acca[0 + b][cg], m1 = acca[6 + b][cg], m2 = acca[12 + b][cg], m3 = acca[18 + b][cg],
-                        m4 = acca[24 + b][cg],
-                        m5 = (30 + b < W4_AGPR_POINTS) ? acca[30 + b < W4_AGPR_POINTS ? 30 + b : 0][cg]
-                                                       : accv[30 + b >= W4_AGPR_POINTS ? 30 + b - W4_AGPR_POINTS : 0][cg];
-            if (h == 0) {
-              const f32x4 s1 = m1 + m2, d1 = w4fma4(m2, k4.m1, m1), s2 = m3 + m4, d2 = w4fma4(m4, k4.m1, m3);
-              z[0][b] = m0 + s1 + s2;
-              z[1][b] = w4fma4(d2, k4.p2, d1);
+          for (int p = 0; p < 4; ++p) {
+            if (b == 0) {
+              o[p][0] = y[p];
+            } else if (b == 1) {
+              o[p][0] = o[p][0] + y[p];
+              o[p][1] = y[p];
+              o[p][2] = y[p];
+              o[p][3] = y[p];
+            } else if (b == 2) {
+              o[p][0] = o[p][0] + y[p];
+              o[p][1] = w4fma4(y[p], k4.m1, o[p][1]);
+              o[p][2] = o[p][2] + y[p];
+              o[p][3] = w4fma4(y[p], k4.m1, o[p][3]);
+            } else if (b == 3) {
+              o[p][0] = o[p][0] + y[p];
+              o[p][1] = w4fma4(y[p], k4.p2, o[p][1]);
+              o[p][2] = w4fma4(y[p], k4.p4, o[p][2]);
+              o[p][3] = w4fma4(y[p], k4.p8, o[p][3]);
+            } else if (b == 4) {
+              o[p][0] = o[p][0] + y[p];
+              o[p][1] = w4fma4(y[p], k4.m2, o[p][1]);
+              o[p][2] = w4fma4(y[p], k4.p4, o[p][2]);
+              o[p][3] = w4fma4(y[p], k4.m8, o[p][3]);
             } else {
-              const f32x4 s1 = m1 + m2, d1 = w4fma4(m2, k4.m1, m1), s2 = m3 + m4, d2 = w4fma4(m4, k4.m1, m3);
-              z[0][b] = w4fma4(s2, k4.p4, s1);
-              z[1][b] = w4fma4(d2, k4.p8, d1) + m5;
+              o[p][3] = o[p][3] + y[p];
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            f32x4 o[4];
-            wino4_at(z[p][0], z[p][1], z[p][2], z[p][3], z[p][4], z[p][5], o, k4);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-              f32x4 vv = o[qq] + sh;
+              f32x4 vv = o[2 * h + p][qq] + sh;
               if (HAS_R) vv = vv + rv[p][qq];
               vv = __builtin_elementwise_max(vv, lo4);
               __builtin_amdgcn_raw_buffer_store_b128(
                   __builtin_bit_cast(u32x4, vv), ysrd,
                   offq[qq] == OOB ? OOB : offq[qq] + (2 * h + p) * srow + 64 * cg, 0, 0);
             }
-          }
           __builtin_amdgcn_sched_barrier(0);
+          if (HAS_R && h == 0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq)
+                rv[p][qq] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                               rsrd, offq[qq] == OOB ? OOB : offq[qq] + (2 + p) * srow + 64 * cg, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
+#undef W4_ACC
     }
+    W4_STAMP(5);
+    W4_STAMP_FLUSH();
     if (nq < 0) break;
     cur = nxt;
     if (tid == 0) claim = tq_claim_own(tq);
@@ -381,6 +517,16 @@ static int launch_wino4(const float* X, int B, int H, int W, int CIN, const floa
 }  // namespace pa
 
 extern "C" {
+
+#if PA_W4_STAMP
+int pa_wino4_read_stamps(unsigned long long* host) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pa::g_w4_stamps), sizeof(unsigned long long) * 8 * 4 * 64 * 6) ==
+                 hipSuccess
+             ? 0
+             : 1;
+}
+#endif
 
 // conv3x3, stride 1, pad 1, via Winograd F(4x4,3x3): Y = [relu](conv(X) + shift [+ R]).  X, R, Y: NHWC float32.
 // U: G g G^T (BatchNorm scale folded) in the slab layout of weights.winograd4_pack / pa_winograd4_pack_host:

@@ -48,6 +48,7 @@ class EmbWeights(C.Structure):
         ("blk_wsc", c_fp * PA_MAX_RES_BLOCKS), ("blk_shiftsc", c_fp * PA_MAX_RES_BLOCKS),
         ("blk_w3", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift3", c_fp * PA_MAX_RES_BLOCKS),
         ("seg1_w", c_fp), ("seg1_b", c_fp),
+        ("blk_v1", c_fp * PA_MAX_RES_BLOCKS), ("blk_v2", c_fp * PA_MAX_RES_BLOCKS),
     ]
 
 

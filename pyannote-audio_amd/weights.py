@@ -485,6 +485,9 @@ def winograd_pack(U: torch.Tensor) -> torch.Tensor:
     return torch.gather(A, 3, idx).contiguous()
 
 
+#: layers that use F(4x4,3x3) by default (set from measurements on MI355X, profiles/r4_wino4_*.txt)
+WINOGRAD4_DEFAULT_LAYERS = ""
+
 #: G of Winograd F(4x4, 3x3) (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf)
 WINOGRAD4_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
                [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]]
@@ -524,6 +527,10 @@ class EmbeddingPack:
         if winograd is None:
             winograd = os.environ.get("PA_WINOGRAD", "1") != "0"
         self.winograd = winograd
+        # ResNet layers (1 .. 4) whose stride-1 3x3 convolutions run through Winograd F(4x4,3x3) instead of F(2x2,3x3)
+        # (csrc/emb_winograd4.hip; BasicBlock networks): PA_WINOGRAD4="" switches it off, "34" = layers 3 and 4
+        self.winograd4_layers = {int(c) for c in os.environ.get("PA_WINOGRAD4", WINOGRAD4_DEFAULT_LAYERS)
+                                 if c in "1234"} if winograd else set()
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
         self.device = device
         self._keep: list[torch.Tensor] = []
@@ -594,6 +601,8 @@ class EmbeddingPack:
                         stride = first_stride if j == 1 else 1
                         if winograd and stride == 1:
                             getattr(w, f"blk_u{j}")[blk] = self._up(winograd_pack(winograd_weights(cw))).value
+                            if l + 1 in self.winograd4_layers and cw.shape[1] >= 32:
+                                getattr(w, f"blk_v{j}")[blk] = self._up(winograd4_pack(winograd4_weights(cw))).value
                 if f"{pre}.shortcut.0.weight" in sd:
                     sc, sh = _fold_bn(sd, f"{pre}.shortcut.1")
                     cw = sd[f"{pre}.shortcut.0.weight"][:, :, 0, 0] * sc.view(-1, 1)

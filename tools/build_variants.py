@@ -7,6 +7,12 @@ sys.path.insert(0, ROOT)
 from pyannote_audio_amd import _build
 
 VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or None for the work tree)
+    "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
+    "w4s_nodma": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NODMA=1", None),     # stamps, no DMA inside the MFMA run
+    "w4s_nouread": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOUREAD=1", None), # stamps, no U reads inside the run
+    "w4s_neither": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NODMA=1 -DPA_W4_NOUREAD=1", None),
+    "w4nopatch": ("emb_winograd4.hip", "-DPA_W4_NOPATCH=1", None),              # F(4x4): no patch traffic (timing only)
+    "w4nomem": ("emb_winograd4.hip", "-DPA_W4_NOPATCH=1 -DPA_W4_NOU=1", None),  # ... nor U traffic
     "stamp": ("emb_winograd.hip", "-DPA_WINO_STAMP=1", None),
     "norefresh": ("emb_winograd.hip", "-DPA_WINO_REFRESH=0", None),   # 128-channel residual kernel without the pinned residual loads
     "nortouch": ("emb_winograd.hip", "-DPA_WINO_RTOUCH=0", None),   # without the residual line touch
