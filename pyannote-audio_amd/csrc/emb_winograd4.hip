@@ -18,7 +18,12 @@
 //     ever hid WAITS -- here there are none left to hide: both LDS images are double-buffered and the DMA of stage
 //     s + 1 (the next tile's first stage behind a tile's last one) is issued right after the barrier that opens
 //     stage s; it has 6 500 cycles to land.
-//   * workgroup tile = 8 x 128 output pixels x 32 output channels; wave w: tile row w >> 1, 16 tile columns;
+//   * a wave owns a UNIT = 16 consecutive tiles of one tile row of one image (4 x 64 output pixels), a workgroup 4
+//     consecutive units x 32 output channels -- any rows of any images, so that maps with an odd number of tile rows
+//     (20 and 10 pixel rows: 5 and 3) leave no wave idle (the first build tiled 8 x 128 pixels per workgroup: one
+//     wave in six / four had nothing to do there).  The patch of a unit is PRIVATE to its wave: no barrier, no
+//     second buffer -- the wave issues the next stage's patch right behind its own input transform; only the U slab
+//     is shared and double-buffered (one barrier per stage).
 //     lane (t = lane & 15, g = lane >> 4): tile t, input-channel pair g of the 8-channel stage.  The lane
 //     transforms the 6x6 patch of its tile for its two channels with packed f32 arithmetic (144 v_pk_* per stage:
 //     B^T x = 12 operations per 6-vector) -- V never touches LDS -- and feeds it to v_mfma_f32_16x16x4_f32 as the B
@@ -30,8 +35,8 @@
 //   * staging is LDS-DMA (buffer_load_dwordx4 ... lds) as in emb_winograd.hip: the patch de-interleaved by column
 //     mod 4 (the 16 lanes of a tile row read consecutive 32-B rows: every ds_read_b64 covers 512 contiguous bytes),
 //     halo and out-of-image columns zero-filled by the buffer bounds check through class bits; U as one contiguous
-//     36-KB image per (32-cout slice, 8-cin stage) (weights.winograd4_pack).
-//   * tiles are claimed at run time (tile_queue.h), in the XCD-aware order of wino_decode.
+//     36-KB image per (32-cout slice, 8-cin stage) (weights.winograd4_pack).  22 pieces of 1 KB per wave and stage.
+//   * groups of 4 units are claimed at run time (tile_queue.h), in an XCD-aware order (wino4_decode).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -48,13 +53,13 @@ namespace pa {
 #if PA_W4_STAMP
 // development instrumentation (never in the product build): s_memtime at the phases of the first 64 stages of
 // workgroups 0 .. 7, per wave; read back with pa_wino4_read_stamps
-__device__ unsigned long long g_w4_stamps[8 * 4 * 64 * 6];
+__device__ unsigned long long g_w4_stamps[8 * 4 * 64 * 10];
 #define W4_STAMP(p) st_[p] = __builtin_amdgcn_s_memtime()
 #define W4_STAMP_FLUSH()                                                                      \
   do {                                                                                        \
     if (blockIdx.x < 8 && st_iter < 64 && lane == 0) {                                         \
-      _Pragma("unroll") for (int p_ = 0; p_ < 6; ++p_)                                         \
-          g_w4_stamps[((blockIdx.x * 4 + slw) * 64 + st_iter) * 6 + p_] = st_[p_];             \
+      _Pragma("unroll") for (int p_ = 0; p_ < 10; ++p_)                                        \
+          g_w4_stamps[((blockIdx.x * 4 + slw) * 64 + st_iter) * 10 + p_] = st_[p_];            \
     }                                                                                         \
     ++st_iter;                                                                                \
   } while (0)
@@ -131,51 +136,65 @@ __device__ __forceinline__ float w4_opaque(float v) {
 struct Wino4Stage {       // wave-uniform
   __amdgpu_buffer_rsrc_t xsrd, usrd;
   int keep, usoff;
-  unsigned char* buf;
+  unsigned char* pbuf;    // this wave's patch block
+  unsigned char* ubuf;    // the U buffer being filled
 };
-__device__ __forceinline__ Wino4Stage wino4_stage(const float* __restrict__ X, int H, int W, int CIN,
-                                                  const float* __restrict__ U, int COUT, const WinoTile& q, int c0,
-                                                  unsigned char* buf, int x0_last) {
+// per (unit, cout slice): everything of a stage's staging that does not depend on the stage (computed once per tile;
+// the stage adds 32 bytes to the patch origin and one slab to the U offset)
+struct Wino4Ctx {
+  const float* xp;   // patch origin of stage 0
+  int xnum;          // bytes from there to the end of the image
+  int keep, usoff;
+};
+__device__ __forceinline__ Wino4Ctx wino4_ctx(const float* __restrict__ X, int H, int W, int CIN, const Wino4Unit& u,
+                                              int n0, int x0_last) {
   using G = Wino4Geom;
   const long img = (long)H * W * CIN;
-  const long org = ((long)(q.y0 - 1) * W + (q.x0 - 1)) * CIN + c0;
-  Wino4Stage st;
-  st.xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + (long)q.b * img + org), 0,
-                                              (int)((img - org) * 4), 0x00020000);
-  st.usrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 36 * COUT * CIN * 4, 0x00020000);
-  st.keep = wino_patch_keep(q, x0_last);
-  st.usoff = ((q.n0 / W_BN) * (CIN / G::CB) + c0 / G::CB) * G::USLAB_BYTES;
+  const long org = ((long)(u.y0 - 1) * W + (u.x0 - 1)) * CIN;
+  Wino4Ctx c;
+  c.xp = X + (long)u.b * img + org;
+  c.xnum = (int)((img - org) * 4);
+  c.keep = wino4_patch_keep(u, x0_last);
+  c.usoff = (n0 / W_BN) * (CIN / G::CB) * G::USLAB_BYTES;
 #ifdef PA_W4_NOPATCH   // development A/B (never in the product build): every patch lane out of bounds -> no traffic
-  st.keep = -1;
+  c.keep = -1;
 #endif
+  return c;
+}
+__device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float* __restrict__ U, int COUT, int CIN,
+                                                  int s, unsigned char* pbuf, unsigned char* ubuf) {
+  using G = Wino4Geom;
+  Wino4Stage st;
+  st.xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.xp + s * G::CB), 0, c.xnum - s * G::CB * 4,
+                                              0x00020000);
+  st.usrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 36 * COUT * CIN * 4, 0x00020000);
+  st.keep = c.keep;
+  st.usoff = c.usoff + s * G::USLAB_BYTES;
 #ifdef PA_W4_NOU       // ... every U piece from slab 0 (L2-resident)
   st.usoff = 0;
 #endif
-  st.buf = buf;
+  st.pbuf = pbuf;
+  st.ubuf = ubuf;
   return st;
 }
-constexpr int W4_PIECES = Wino4Geom::NPP + 9;
-struct Wino4Lanes {       // per-lane patch offsets + class bits (wino4_patch_lanes), one per piece of this wave
-  int a[Wino4Geom::NPP];
+constexpr int W4_PIECES = Wino4Geom::PINSTR + 9;   // 13 of the wave's patch + its 9 of the 36 U pieces
+struct Wino4Lanes {       // per-lane patch offsets + class bits (wino4_patch_lanes), one per patch piece
+  int a[Wino4Geom::PINSTR];
 };
 // (I is a compile-time constant at every call site after unrolling)
 __device__ __forceinline__ void wino4_piece(const int I, const Wino4Stage& st, const Wino4Lanes& pl, int lane,
                                             int slw) {
   using G = Wino4Geom;
-  if (I < G::NPP) {
-    const int k = slw + 4 * I;
-    const int* prel = pl.a;
-    if (k < G::PINSTR)   // wave-uniform
+  if (I < G::PINSTR) {
 #ifdef PA_W4_NOPATCH
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.buf + 1024 * k), 16, prel[I] | WCLS_PAD, 0, 0,
-                                               0);
+    const int off = pl.a[I < G::PINSTR ? I : 0] | WCLS_PAD;
 #else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.buf + 1024 * k), 16, prel[I] & st.keep, 0, 0,
-                                               0);
+    const int off = pl.a[I < G::PINSTR ? I : 0] & st.keep;
 #endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.pbuf + 1024 * I), 16, off, 0, 0, 0);
   } else {
-    const int k = slw + 4 * (I - G::NPP);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.usrd, (lds4_ptr_t)(st.buf + G::PATCH_BYTES + 1024 * k), 16, lane * 16,
+    const int k = slw + 4 * (I - G::PINSTR);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.usrd, (lds4_ptr_t)(st.ubuf + 1024 * k), 16, lane * 16,
                                              st.usoff + 1024 * k, 0, 0);
   }
 }
@@ -188,16 +207,18 @@ template <bool HAS_R>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT, int relu,
-    int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb, int* __restrict__ counters) {
+    int cgroups, int trows, int num_units, int num_groups, int n_tiles, int total_work,
+    int* __restrict__ counters) {
   using G = Wino4Geom;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int t = lane & 15, g = lane >> 4;
   const int slw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = slw >> 1, wc = slw & 1;
-  int* mail = reinterpret_cast<int*>(smem4 + 2 * G::BUF_BYTES);
+  unsigned char* my_patch = smem4 + slw * G::PATCH_BYTES;
+  unsigned char* ubufs = smem4 + 4 * G::PATCH_BYTES;
+  int* mail = reinterpret_cast<int*>(smem4 + G::LDS_BYTES);
 
-  const TileQueue tq{counters, (int)(blockIdx.x & 7), total_tiles >> 3};
+  const TileQueue tq{counters, (int)(blockIdx.x & 7), total_work >> 3};
   if (tid == 0) mail[0] = tq_resolve(tq, tq_claim_own(tq));
   __syncthreads();
   int q = mail[0];
@@ -205,10 +226,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     if (tid == 0) tq_done(tq, gridDim.x);
     return;
   }
-  const int x0_last = (tiles_w - 1) * G::TW;
+  const int x0_last = (cgroups - 1) * G::TW;
   Wino4Lanes pl;
-  wino4_patch_lanes(pl.a, W, CIN, lane, slw, x0_last);
-  const int pbase = wino4_patch_base(t, g, wr, wc);
+  wino4_patch_lanes(pl.a, W, CIN, lane, x0_last);
+  const int pbase = wino4_patch_base(t, g);
   const int ubase = wino4_u_base(t, g);
   W4Const kc;
   {
@@ -219,9 +240,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   }
   const int nstages = CIN / G::CB;
 
-  WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, G::TH, G::TW, num_pb), nxt = cur;
+  // this wave's unit of the claimed group (a group past the end / a unit past the last one is computed on the last
+  // real unit's data and not stored: valid = 0)
+  Wino4Work wk = wino4_decode(q, n_tiles, num_groups);
+  Wino4Unit cur = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units), nxt = cur;
+  cur.valid &= wk.valid;
+  int cur_n0 = wk.n0, nxt_n0 = wk.n0;
+  Wino4Ctx cctx = wino4_ctx(X, H, W, CIN, cur, cur_n0, x0_last), nctx = cctx;
   int buf = 0;
-  wino4_issue_all(wino4_stage(X, H, W, CIN, U, COUT, cur, 0, smem4, x0_last), pl, lane, slw);
+  wino4_issue_all(wino4_stage(cctx, U, COUT, CIN, 0, my_patch, ubufs), pl, lane, slw);
   int claim = 0;
   if (tid == 0) claim = tq_claim_own(tq);
   int nq = -1;
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   f32x4 accv[36 - W4_AGPR_POINTS][2];   // points 32 .. 35: architectural registers
 
 #if PA_W4_STAMP
-  unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int st_iter = 0;
 #endif
   while (true) {
@@ -237,28 +264,39 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       W4_STAMP(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
       W4_STAMP(1);
+      // the claim of the NEXT group was issued at the start of this tile: its value is picked up here, behind the
+      // wait above (anywhere else the compiler's own vmcnt wait for it would also wait for staging in flight), and
+      // published by the barrier that opens the tile's last stage
+      if (s == nstages - 1 && tid == 0) mail[0] = tq_resolve(tq, claim);
       wino4_barrier();                                    // ... everybody's; and everybody is done with the other buffer
       W4_STAMP(2);
-      unsigned char* mine = smem4 + buf * G::BUF_BYTES;
-      unsigned char* other = smem4 + (buf ^ 1) * G::BUF_BYTES;
-      // what the MFMA run below stages: the next stage of this tile, or the first stage of the next one
+      unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
+      unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
+      // what the MFMA run below stages: the next stage of this unit, or the first stage of the next group's unit
       bool stage_next = true;
       Wino4Stage nst;
+
       if (s + 1 < nstages) {
-        nst = wino4_stage(X, H, W, CIN, U, COUT, cur, (s + 1) * G::CB, other, x0_last);
+        nst = wino4_stage(cctx, U, COUT, CIN, s + 1, my_patch, uother);
       } else {
         nq = mail[0];   // (written by thread 0 in front of this stage's barrier)
         stage_next = nq >= 0;
-        nxt = wino_decode(stage_next ? nq : 0, tiles_w, tiles_hw, n_tiles, G::TH, G::TW, num_pb);
-        nst = wino4_stage(X, H, W, CIN, U, COUT, nxt, 0, other, x0_last);
+        wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups);
+        nxt = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
+        nxt.valid &= wk.valid;
+        nxt_n0 = wk.n0;
+        nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
+        nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
+
       }
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
       {
-        const unsigned char* pb = mine + pbase;
+        const unsigned char* pb = my_patch + pbase;
         f32x2 tt[6][6];
         // columns of d: tt[.][j] = B^T d[.][j]; column j + 1 is read while column j is combined (left alone, the
-        // scheduler issues all 36 reads first and the 72 extra registers spill)
+        // scheduler issues all 36 reads first and the 72 extra registers spill).  (Two columns between the barriers
+        // were measured SLOWER: 2 745 instead of 1 700 cycles for setup + transform.)
         f32x2 x[2][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[0][i] = *reinterpret_cast<const f32x2*>(pb + wino4_patch_k(i, 0));
@@ -291,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // registers (left to the register allocator, 288 accumulators + the transform spill ~200 registers).
       auto mfma_run = [&](auto first_stage) {
         constexpr bool FIRST = decltype(first_stage)::value;
-        const unsigned char* ub = mine + G::PATCH_BYTES + ubase;
+        const unsigned char* ub = umine + ubase;
         f32x2 uf[2][2][2];   // [pair parity][point of the pair][channel group]
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -347,7 +385,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       if (s == 0) mfma_run(std::true_type{});
       else mfma_run(std::false_type{});
       W4_STAMP(4);
-      if (s == nstages - 2 && tid == 0) mail[0] = tq_resolve(tq, claim);   // published by the next barrier
       buf ^= 1;
       if (s + 1 < nstages) {
         W4_STAMP(5);
@@ -370,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<float*>(HAS_R ? R + (long)cur.b * H * W * COUT : Y), 0, H * W * COUT * 4, 0x00020000);
       constexpr int OOB = (int)0x80000000;
-      const int xl = cur.x0 + 64 * wc + 4 * t;
-      const int obase = (((cur.y0 + 4 * wr) * W + xl) * COUT + cur.n0 + 4 * g) * 4;
+      const int xl = cur.x0 + 4 * t;
+      const int obase = ((cur.y0 * W + xl) * COUT + cur_n0 + 4 * g) * 4;
       const int srow = W * COUT * 4, spix = COUT * 4;
       int offq[4];
 #pragma unroll
@@ -386,9 +423,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
                                           : accv[(xi) >= W4_AGPR_POINTS ? (xi)-W4_AGPR_POINTS : 0][cg])
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + cur.n0 + 16 * cg + 4 * g);
-        f32x4 rv[2][4];
-        if (HAS_R) {   // rows 0-1 now (their latency hides under the inverse transform), rows 2-3 behind them
+        // BN shift of this lane's four channels, through the SCALAR cache (uniform address, lgkmcnt): a vector load
+        // here would make the epilogue wait on vmcnt -- behind the next tile's staging and this tile's stores
+        f32x4 sh;
+        {
+          const float* sp = shift + cur_n0 + 16 * cg;
+          float s16[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s16[i] = sp[i];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sh[r] = g == 0 ? s16[r] : (g == 1 ? s16[4 + r] : (g == 2 ? s16[8 + r] : s16[12 + r]));
+        }
+        f32x4 rv[4][4];
+        if (HAS_R) {   // rows 0-1 now, rows 2-3 half way through the columns: their latency hides under the arithmetic
 #pragma unroll
           for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -406,8 +454,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           //  binds the machine scheduler -- and 288 live registers spill)
 #pragma unroll
           for (int a6 = 0; a6 < 6; ++a6) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int xi = 6 * a6 + b;
             if (xi < W4_AGPR_POINTS) asm volatile("" : "+a"(acca[xi < W4_AGPR_POINTS ? xi : 0][cg]));
           }
@@ -442,33 +488,45 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
               o[p][3] = o[p][3] + y[p];
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+          // (two columns between barriers: one column alone is a dependency chain a single wave cannot fill)
+          if (b & 1) __builtin_amdgcn_sched_barrier(0);
+          if (HAS_R && b == 3) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-          for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-              f32x4 vv = o[2 * h + p][qq] + sh;
-              if (HAS_R) vv = vv + rv[p][qq];
-              vv = __builtin_elementwise_max(vv, lo4);
-              __builtin_amdgcn_raw_buffer_store_b128(
-                  __builtin_bit_cast(u32x4, vv), ysrd,
-                  offq[qq] == OOB ? OOB : offq[qq] + (2 * h + p) * srow + 64 * cg, 0, 0);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-          if (HAS_R && h == 0) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 2; p < 4; ++p)
 #pragma unroll
               for (int qq = 0; qq < 4; ++qq)
                 rv[p][qq] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                               rsrd, offq[qq] == OOB ? OOB : offq[qq] + (2 + p) * srow + 64 * cg, 0, 0));
+                               rsrd, offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#if PA_W4_STAMP
+        asm volatile("s_nop 0" ::"v"(o[3][3]), "v"(o[0][0]));
+        st_[6 + 2 * cg] = __builtin_amdgcn_s_memtime();
+#endif
+        // all 16 outputs of the channel group are finished FIRST and then stored from 16 different register quads: a
+        // store reads its data when the memory pipe gets to it, and a vector write that recycles the same registers
+        // for the next output waits for that (first build: one quad for all 16 stores, 3 300 cycles per group)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            o[p][qq] = o[p][qq] + sh;
+            if (HAS_R) o[p][qq] = o[p][qq] + rv[p][qq];
+            o[p][qq] = __builtin_elementwise_max(o[p][qq], lo4);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd,
+                                                   offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#if PA_W4_STAMP
+        st_[7 + 2 * cg] = __builtin_amdgcn_s_memtime();
+#endif
       }
 #undef W4_ACC
     }
@@ -476,6 +534,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     W4_STAMP_FLUSH();
     if (nq < 0) break;
     cur = nxt;
+    cur_n0 = nxt_n0;
+    cctx = nctx;
     if (tid == 0) claim = tq_claim_own(tq);
   }
   if (tid == 0) tq_done(tq, gridDim.x);
@@ -485,8 +545,8 @@ template <bool HAS_R>
 static int launch_wino4(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                         const float* R, float* Y, int COUT, int relu, hipStream_t st) {
   using G = Wino4Geom;
-  const int tiles_w = cdiv(W, G::TW), tiles_h = cdiv(H, G::TH);
-  const size_t lds = 2 * (size_t)G::BUF_BYTES + 16;
+  const int cgroups = cdiv(W, G::TW), trows = cdiv(H, G::TH);
+  const size_t lds = (size_t)G::LDS_BYTES + 16;
   auto kernel = k_conv3x3_wino4<HAS_R>;
   constexpr int MAXDEV = 16;
   static int cus_of[MAXDEV] = {0};
@@ -499,18 +559,19 @@ static int launch_wino4(const float* X, int B, int H, int W, int CIN, const floa
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     cus_of[dev] = cus;
   }
-  const int tiles_hw = tiles_w * tiles_h, n_tiles = COUT / W_BN;
-  const long num_pb = (long)tiles_hw * B;
-  const long total = ((num_pb + 7) / 8) * 8 * n_tiles;
-  const int resident = cus_of[dev] & ~7;             // one workgroup per CU
+  const int n_tiles = COUT / W_BN;
+  const long num_units = (long)cgroups * trows * B;
+  const long num_groups = (num_units + 3) / 4;
+  const long total = ((num_groups + 7) / 8) * 8 * n_tiles;   // padded to whole XCD stripes
+  const int resident = cus_of[dev] & ~7;                      // one workgroup per CU
   const int grid = (int)(total < resident ? total : resident);
   int* counters = tile_counters();
   if (counters == nullptr) {
     set_error("pa_conv3x3_wino4: cannot allocate the tile counters");
     return 2;
   }
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, tiles_w,
-                     tiles_hw, n_tiles, (int)total, (int)num_pb, counters);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, cgroups, trows,
+                     (int)num_units, (int)num_groups, n_tiles, (int)total, counters);
   return 0;
 }
 
@@ -521,7 +582,7 @@ extern "C" {
 #if PA_W4_STAMP
 int pa_wino4_read_stamps(unsigned long long* host) {
   (void)hipDeviceSynchronize();
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pa::g_w4_stamps), sizeof(unsigned long long) * 8 * 4 * 64 * 6) ==
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pa::g_w4_stamps), sizeof(unsigned long long) * 8 * 4 * 64 * 10) ==
                  hipSuccess
              ? 0
              : 1;

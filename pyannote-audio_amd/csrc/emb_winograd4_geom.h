@@ -1,45 +1,52 @@
 // Integer geometry of the Winograd F(4x4, 3x3) convolution kernel (csrc/emb_winograd4.hip): LDS layouts, the
-// per-lane DMA offsets with their halo class bits, the transform's read addresses.  No HIP types: the header is
-// also compiled for the HOST by tests/test_winograd4_geometry_cpu.py, which replays the DMA and the transform reads
-// of every wave and lane and checks that they agree (and that the reads are bank-conflict free).
-// Needs: __device__, __forceinline__, and emb_winograd_geom.h (WinoTile, the class bits, wino_decode).
+// per-lane DMA offsets with their halo class bits, the transform's read addresses, the unit order.  No HIP types: the
+// header is also compiled for the HOST by tests/test_winograd_geometry_cpu.py (tests/native/
+// winograd4_geom_harness.cpp), which replays the DMA and the transform reads of every lane and checks that they agree
+// (and that the reads are bank-conflict free).
+// Needs: __device__, __forceinline__, and emb_winograd_geom.h (the class bits, W_BN).
 #pragma once
 
 namespace pa {
 
-// Workgroup tile: 8 x 128 output pixels x 32 output channels = 2 rows x 32 columns of 4x4 Winograd tiles; wave w
-// owns tile row wr = w >> 1 and the 16 tile columns 16 wc .., wc = w & 1.  A stage stages 8 input channels:
-//   patch  10 x 130 input pixels x 8 channels (one pixel = one 32-B LDS row), de-interleaved by column mod 4 so
-//          that the 16 lanes of a tile row, 4 pixels apart, read CONSECUTIVE rows: row = (py*4 + px%4)*33 + px/4;
-//   U slab 36 points x 32 output channels x 8 input channels: row = 32 xi + n (32 B = the 8 input channels).
+// A WAVE owns one "unit" = 16 consecutive 4x4 Winograd tiles of one tile row of one image: 4 x 64 output pixels; a
+// workgroup = 4 waves = 4 consecutive units (any rows, any images) x the same 32 output channels.  A stage stages 8
+// input channels:
+//   patch  (PRIVATE to the wave: no other wave reads it, so it needs no barrier and no second buffer -- the wave
+//          issues the next stage's patch right behind its own input transform) 6 x 66 input pixels x 8 channels, one
+//          pixel = one 32-B LDS row, de-interleaved by column mod 4 so that the 16 lanes of the tile row, 4 pixels
+//          apart, read CONSECUTIVE rows: row = (py*4 + px%4)*17 + px/4;
+//   U slab (shared by the 4 waves, double-buffered) 36 points x 32 output channels x 8 input channels:
+//          row = 32 xi + n (32 B = the 8 input channels).
 struct Wino4Geom {
   static constexpr int CB = 8;                       // input channels per stage
-  static constexpr int TH = 8, TW = 128;             // output pixels per workgroup tile
+  static constexpr int TH = 4, TW = 64;              // output pixels per unit
   static constexpr int PH = TH + 2, PW = TW + 2;     // patch
-  static constexpr int PWQ = (PW + 3) / 4;           // 33 entries per column residue
-  static constexpr int PROWS = PH * 4 * PWQ;         // 1320 LDS rows of 32 B
-  static constexpr int PINSTR = (PROWS + 31) / 32;   // 42 DMA pieces of 1 KB (32 rows)
-  static constexpr int NPP = (PINSTR + 3) / 4;       // 11 per wave
-  static constexpr int PATCH_BYTES = PINSTR * 1024;  // 43 008
-  static constexpr int UINSTR = 36;                  // 36 x 1 KB
+  static constexpr int PWQ = (PW + 3) / 4;           // 17 entries per column residue
+  static constexpr int PROWS = PH * 4 * PWQ;         // 408 LDS rows of 32 B
+  static constexpr int PINSTR = (PROWS + 31) / 32;   // 13 DMA pieces of 1 KB (32 rows) per wave and stage
+  static constexpr int PATCH_BYTES = PINSTR * 1024;  // 13 312 per wave
+  static constexpr int UINSTR = 36;                  // 36 x 1 KB per workgroup and stage: 9 per wave
   static constexpr int USLAB_BYTES = 36 * 32 * CB * 4;   // 36 864
-  static constexpr int BUF_BYTES = PATCH_BYTES + USLAB_BYTES;   // one stage: 79 872 (two buffers: 159 744)
+  static constexpr int LDS_BYTES = 4 * PATCH_BYTES + 2 * USLAB_BYTES;   // 126 976
 };
 
-// Patch DMA: piece k fills LDS rows 32k .. 32k+31; lane l -> row 32k + (l >> 1), channel quad l & 1.
-// `prel` = byte offset of the lane's (patch pixel, quad) from the patch origin (y0 - 1, x0 - 1) + class bits (see
-// emb_winograd_geom.h): top halo row, left halo column, every column at or right of the image border in the LAST
-// column tile (F(4x4) mixes all six patch columns into every output of a tile: columns past the border must be
-// zeros, not the next row's pixels), padding lanes.
-__device__ __forceinline__ void wino4_patch_lanes(int* prel, int W, int CIN, int lane, int slw, int x0_last) {
+struct Wino4Unit {   // wave-uniform
+  int b, y0, x0, valid;
+};
+
+// Patch DMA of one wave: piece i fills LDS rows 32i .. 32i+31 of the wave's block; lane l -> row 32i + (l >> 1),
+// channel quad l & 1.  `prel` = byte offset of the lane's (patch pixel, quad) from the patch origin (y0 - 1, x0 - 1) +
+// class bits (emb_winograd_geom.h): top halo row, left halo column, every column at or right of the image border in
+// the LAST column group (F(4x4) mixes all six patch columns into every output of a tile: columns past the border
+// must be zeros, not the next row's pixels), padding lanes.
+__device__ __forceinline__ void wino4_patch_lanes(int* prel, int W, int CIN, int lane, int x0_last) {
   using G = Wino4Geom;
 #pragma unroll
-  for (int i = 0; i < G::NPP; ++i) {
-    const int k = slw + 4 * i;
-    const int row = 32 * k + (lane >> 1);
+  for (int i = 0; i < G::PINSTR; ++i) {
+    const int row = 32 * i + (lane >> 1);
     const int pr = row / G::PWQ, idx = row % G::PWQ;   // pr = py*4 + residue
     const int py = pr >> 2, px = 4 * idx + (pr & 3);
-    const bool real = k < G::PINSTR && row < G::PROWS && px < G::PW;
+    const bool real = row < G::PROWS && px < G::PW;
     int v = ((py * W + px) * CIN + 4 * (lane & 1)) * 4;
     if (py == 0) v |= WCLS_TOP;
     if (px == 0) v |= WCLS_LEFT;
@@ -47,18 +54,50 @@ __device__ __forceinline__ void wino4_patch_lanes(int* prel, int W, int CIN, int
     prel[i] = real ? v : WCLS_PAD;
   }
 }
-
-// Patch reads of the input transform: tile (wr, 16 wc + t), patch element (i, j), channel pair g: byte address
-// base(lane) + K_ij with base = 32 (16 wr * 33 + 16 wc + t) + 8 g and K_ij = 32 ((4 i + (j & 3)) * 33 + (j >> 2))
-// (compile time: a ds_read_b64 immediate).  The 64 lanes of one read cover 512 contiguous bytes.
-__device__ __forceinline__ int wino4_patch_base(int t, int g, int wr, int wc) {
-  return 32 * (16 * wr * Wino4Geom::PWQ + 16 * wc + t) + 8 * g;
+// class bits that stay SET for a unit (offset past num_records -> the DMA writes zeros)
+__device__ __forceinline__ int wino4_patch_keep(const Wino4Unit& u, int x0_last) {
+  int keep = 0x0fffffff;
+  if (u.y0 == 0) keep |= WCLS_TOP;
+  if (u.x0 == 0) keep |= WCLS_LEFT;
+  if (u.x0 == x0_last) keep |= WCLS_RIGHT;
+  return keep | WCLS_PAD;
 }
+
+// Patch reads of the input transform: tile t, patch element (i, j), channel pair g: byte address (within the wave's
+// block) 32 t + 8 g + K_ij, K_ij = 32 ((4 i + (j & 3)) * 17 + (j >> 2)) (compile time: a ds_read_b64 immediate).
+// The 64 lanes of one read cover 512 contiguous bytes.
+__device__ __forceinline__ int wino4_patch_base(int t, int g) { return 32 * t + 8 * g; }
 constexpr int wino4_patch_k(int i, int j) { return 32 * ((4 * i + (j & 3)) * Wino4Geom::PWQ + (j >> 2)); }
 
 // U reads of the MFMA A operand: lane (m = lane & 15, g = lane >> 4) reads the input-channel pair g of output
 // channel 16 cg + m at point xi: base 32 m + 8 g, offset 1024 xi + 512 cg.
 __device__ __forceinline__ int wino4_u_base(int m, int g) { return 32 * m + 8 * g; }
 constexpr int wino4_u_k(int xi, int cg) { return 1024 * xi + 512 * cg; }
+
+// Unit u of an (B, H, W) map: column group fastest, then tile row, then image -- the 4 units of a workgroup are
+// neighbours.  Work item q of the launch (XCD-aware like wino_decode: q % 8 = XCD, the n_tiles cout slices of one
+// group of 4 units side by side on one XCD): -> first unit of the group and the cout slice.
+struct Wino4Work {
+  int unit0, n0, valid;
+};
+__device__ __forceinline__ Wino4Work wino4_decode(int q, int n_tiles, int num_groups) {
+  Wino4Work o;
+  const int xcd = q & 7, r = q >> 3;
+  const int grp = (r / n_tiles) * 8 + xcd;
+  o.n0 = (r % n_tiles) * W_BN;
+  o.valid = grp < num_groups;
+  o.unit0 = 4 * (grp < num_groups ? grp : num_groups - 1);
+  return o;
+}
+__device__ __forceinline__ Wino4Unit wino4_unit(int u, int cgroups, int trows, int num_units) {
+  Wino4Unit o;
+  o.valid = u < num_units;
+  const int uu = u < num_units ? u : num_units - 1;
+  const int c = uu % cgroups, r = (uu / cgroups) % trows;
+  o.b = uu / (cgroups * trows);
+  o.y0 = 4 * r;
+  o.x0 = 64 * c;
+  return o;
+}
 
 }  // namespace pa

@@ -485,8 +485,10 @@ def winograd_pack(U: torch.Tensor) -> torch.Tensor:
     return torch.gather(A, 3, idx).contiguous()
 
 
-#: layers that use F(4x4,3x3) by default (set from measurements on MI355X, profiles/r4_wino4_*.txt)
-WINOGRAD4_DEFAULT_LAYERS = ""
+#: layers that use F(4x4,3x3) by default, from measurements on MI355X (profiles/r4_wino4_anatomy.txt; one audio-hour
+#: per step: F(2x2) everywhere 883 ms, "3" 859, "34" 852, "234" 848; the 32-channel layer 1 is faster with F(2x2):
+#: its tiles have only four 8-channel stages to amortise the F(4x4) epilogue, and it is close to HBM-bound)
+WINOGRAD4_DEFAULT_LAYERS = "234"
 
 #: G of Winograd F(4x4, 3x3) (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf)
 WINOGRAD4_G = [[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],

@@ -1,11 +1,12 @@
 // Host harness for csrc/emb_winograd4_geom.h (the integer geometry of k_conv3x3_wino4, compiled unchanged):
-// replays, for every wave and lane, (1) the LDS-DMA of the input patch -- which global element, or a hardware zero,
-// lands in which 16-byte LDS slot -- and (2) the ds_read_b64 addresses of the input transform, and checks that
+// replays, for every lane of a wave, (1) the LDS-DMA of the wave's input patch -- which global element, or a hardware
+// zero, lands in which 16-byte LDS slot -- and (2) the ds_read_b64 addresses of the input transform, and checks that
 // every read returns exactly the patch element (pixel, channel pair) the Winograd tile needs, zeros wherever the
 // pixel lies outside the image (F(4x4) mixes all six patch columns into every output of a tile, so EVERY column
 // past the border must be a zero, not only the first), that no read touches an LDS location the DMA did not write,
 // and that the 64 lanes of one read cover 512 contiguous bytes (bank-conflict free at two passes).  Same for the
-// U-slab reads.  Exit code 0 = all good.
+// U-slab reads; and the unit order hands out every (unit, cout slice) exactly once, the slices of a group of four
+// units on one XCD.  Exit code 0 = all good.
 #include <cstdio>
 #include <cstdlib>
 #include <set>
@@ -22,76 +23,69 @@ struct Cell {
   int quad;      // channel quad 0..1 of the 8-channel stage
 };
 
-static int check_tile(int H, int W, int CIN, int y0, int x0, int x0_last, int c0) {
+static int check_unit(int H, int W, int CIN, int y0, int x0, int x0_last, int c0) {
   using G = Wino4Geom;
-  WinoTile q{0, 0, y0, x0, 1};
+  Wino4Unit u{0, y0, x0, 1};
   const long img = (long)H * W * CIN;
   const long org = ((long)(y0 - 1) * W + (x0 - 1)) * CIN + c0;
   const unsigned num_records = (unsigned)((img - org) * 4);
-  std::vector<Cell> lds((size_t)G::PINSTR * 64, Cell{0, 0, 0});   // 16-byte slots
-  const int keep = wino_patch_keep(q, x0_last);
-  for (int slw = 0; slw < 4; ++slw)
-    for (int lane = 0; lane < 64; ++lane) {
-      int prel[G::NPP];
-      wino4_patch_lanes(prel, W, CIN, lane, slw, x0_last);
-      for (int i = 0; i < G::NPP; ++i) {
-        const int k = slw + 4 * i;
-        if (k >= G::PINSTR) break;
-        const unsigned off = (unsigned)(prel[i] & keep);
-        Cell& c = lds[(size_t)64 * k + lane];
-        if (c.kind != 0) return printf("LDS location written twice\n"), 1;
-        if (off >= num_records) {
-          c = Cell{1, 0, 0};
-        } else {
-          const long fl = (long)(off / 4) + org - c0;
-          if (fl < 0 || (off % 16) != 0) return printf("bad offset\n"), 1;
-          c = Cell{2, fl / CIN, (int)(fl % CIN) / 4};
-          if ((fl % CIN) % 4 != 0 || (fl % CIN) >= G::CB) return printf("channel quad out of the stage\n"), 1;
-        }
+  std::vector<Cell> lds((size_t)G::PINSTR * 64, Cell{0, 0, 0});   // 16-byte slots of the wave's block
+  const int keep = wino4_patch_keep(u, x0_last);
+  for (int lane = 0; lane < 64; ++lane) {
+    int prel[G::PINSTR];
+    wino4_patch_lanes(prel, W, CIN, lane, x0_last);
+    for (int i = 0; i < G::PINSTR; ++i) {
+      const unsigned off = (unsigned)(prel[i] & keep);
+      Cell& c = lds[(size_t)64 * i + lane];
+      if (c.kind != 0) return printf("LDS location written twice\n"), 1;
+      if (off >= num_records) {
+        c = Cell{1, 0, 0};
+      } else {
+        const long fl = (long)(off / 4) + org - c0;
+        if (fl < 0 || (off % 16) != 0) return printf("bad offset\n"), 1;
+        c = Cell{2, fl / CIN, (int)(fl % CIN) / 4};
+        if ((fl % CIN) % 4 != 0 || (fl % CIN) >= G::CB) return printf("channel quad out of the stage\n"), 1;
       }
     }
-  for (int slw = 0; slw < 4; ++slw) {
-    const int wr = slw >> 1, wc = slw & 1;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        std::set<int> bytes;
-        int lo = 1 << 30, hi = 0;
-        for (int lane = 0; lane < 64; ++lane) {
-          const int t = lane & 15, g = lane >> 4;
-          const int addr = wino4_patch_base(t, g, wr, wc) + wino4_patch_k(i, j);
-          if (addr % 8 != 0 || addr / 16 >= (int)lds.size()) return printf("read outside the patch image\n"), 1;
-          lo = addr < lo ? addr : lo;
-          hi = addr > hi ? addr : hi;
-          bytes.insert(addr);
-          const Cell& c = lds[addr / 16];
-          const int py = 4 * wr + i, px = 4 * (16 * wc + t) + j;
-          const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-          if (c.kind == 0) return printf("read of an LDS location the DMA never wrote (i=%d j=%d lane=%d)\n", i, j, lane), 1;
-          const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          if (inside) {
-            // the 8-byte read takes channels 2g, 2g+1: quad g >> 1, second half of the slot when g is odd
-            if (c.kind != 2 || c.gpix != (long)iy * W + ix || c.quad != (g >> 1) || ((addr % 16) / 8) != (g & 1))
-              return printf("tile (%d,%d) wave %d lane %d (i=%d,j=%d): wrong element\n", y0, x0, slw, lane, i, j), 1;
-          } else {
-            if (c.kind != 1) return printf("element (%d,%d) outside the image is not a hardware zero\n", iy, ix), 1;
-          }
-        }
-        if (bytes.size() != 64 || hi - lo != 504) return printf("transform read (i=%d,j=%d) is not 512 contiguous bytes\n", i, j), 1;
-      }
   }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      std::set<int> bytes;
+      int lo = 1 << 30, hi = 0;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int t = lane & 15, g = lane >> 4;
+        const int addr = wino4_patch_base(t, g) + wino4_patch_k(i, j);
+        if (addr % 8 != 0 || addr / 16 >= (int)lds.size()) return printf("read outside the patch block\n"), 1;
+        lo = addr < lo ? addr : lo;
+        hi = addr > hi ? addr : hi;
+        bytes.insert(addr);
+        const Cell& c = lds[addr / 16];
+        const int iy = y0 - 1 + i, ix = x0 - 1 + 4 * t + j;
+        if (c.kind == 0) return printf("read of an LDS location the DMA never wrote (i=%d j=%d lane=%d)\n", i, j, lane), 1;
+        const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (inside) {
+          // the 8-byte read takes channels 2g, 2g+1: quad g >> 1, second half of the slot when g is odd
+          if (c.kind != 2 || c.gpix != (long)iy * W + ix || c.quad != (g >> 1) || ((addr % 16) / 8) != (g & 1))
+            return printf("unit (%d,%d) lane %d (i=%d,j=%d): wrong element\n", y0, x0, lane, i, j), 1;
+        } else {
+          if (c.kind != 1) return printf("element (%d,%d) outside the image is not a hardware zero\n", iy, ix), 1;
+        }
+      }
+      if (bytes.size() != 64 || hi - lo != 504) return printf("transform read (i=%d,j=%d) is not 512 contiguous bytes\n", i, j), 1;
+    }
   return 0;
 }
 
 static int check_image(int H, int W, int CIN) {
   using G = Wino4Geom;
-  const int tiles_h = (H + G::TH - 1) / G::TH, tiles_w = (W + G::TW - 1) / G::TW;
-  const int x0_last = (tiles_w - 1) * G::TW;
-  for (int ty = 0; ty < tiles_h; ++ty)
-    for (int tx = 0; tx < tiles_w; ++tx) {
-      if (ty > 1 && ty < tiles_h - 2 && tx > 1 && tx < tiles_w - 2 && (ty * 7 + tx) % 5) continue;
+  const int trows = (H + G::TH - 1) / G::TH, cgroups = (W + G::TW - 1) / G::TW;
+  const int x0_last = (cgroups - 1) * G::TW;
+  for (int r = 0; r < trows; ++r)
+    for (int c = 0; c < cgroups; ++c) {
+      if (r > 1 && r < trows - 2 && c > 1 && c < cgroups - 2 && (r * 7 + c) % 5) continue;
       for (int c0 = 0; c0 < CIN; c0 += CIN - G::CB > 0 ? CIN - G::CB : G::CB)
-        if (check_tile(H, W, CIN, ty * G::TH, tx * G::TW, x0_last, c0)) {
-          printf("  image %dx%dx%d tile (%d,%d) stage %d\n", H, W, CIN, ty, tx, c0);
+        if (check_unit(H, W, CIN, r * G::TH, c * G::TW, x0_last, c0)) {
+          printf("  image %dx%dx%d unit (%d,%d) stage %d\n", H, W, CIN, r, c, c0);
           return 1;
         }
     }
@@ -115,11 +109,38 @@ static int check_u_reads() {
   return 0;
 }
 
+static int check_order(int B, int H, int W, int n_tiles) {
+  using G = Wino4Geom;
+  const int trows = (H + G::TH - 1) / G::TH, cgroups = (W + G::TW - 1) / G::TW;
+  const int num_units = B * trows * cgroups, num_groups = (num_units + 3) / 4;
+  const int total = ((num_groups + 7) / 8) * 8 * n_tiles;
+  std::vector<int> seen((size_t)num_units * n_tiles, 0);
+  for (int q = 0; q < total; ++q) {
+    const Wino4Work w = wino4_decode(q, n_tiles, num_groups);
+    if (w.n0 % W_BN || w.n0 / W_BN >= n_tiles || w.unit0 % 4 || w.unit0 / 4 >= num_groups) return printf("decode out of range\n"), 1;
+    if (w.valid && ((w.unit0 / 4) & 7) != (q & 7)) return printf("group %d is not on XCD %d\n", w.unit0 / 4, q & 7), 1;
+    for (int s = 0; s < 4; ++s) {
+      Wino4Unit u = wino4_unit(w.unit0 + s, cgroups, trows, num_units);
+      u.valid &= w.valid;
+      if (u.b < 0 || u.b >= B || u.y0 % 4 || u.y0 >= H || u.x0 % 64 || u.x0 >= W) return printf("unit out of the map\n"), 1;
+      if (!u.valid) continue;
+      const int idx = (u.b * trows + u.y0 / 4) * cgroups + u.x0 / 64;
+      if (idx != w.unit0 + s) return printf("unit decode is not the inverse of the unit order\n"), 1;
+      seen[(size_t)idx * n_tiles + w.n0 / W_BN]++;
+    }
+  }
+  for (int v : seen)
+    if (v != 1) return printf("a (unit, cout slice) pair is handed out %d times\n", v), 1;
+  return 0;
+}
+
 int main() {
-  static_assert(2 * Wino4Geom::BUF_BYTES + 16 <= 160 * 1024, "two stage buffers must fit the 160 KB of LDS");
+  static_assert(Wino4Geom::LDS_BYTES + 16 <= 160 * 1024, "patch blocks + two U buffers must fit the 160 KB of LDS");
   const int images[][3] = {{80, 998, 32}, {40, 499, 64}, {20, 250, 128}, {10, 125, 256}, {17, 9, 32}, {1, 1, 64},
-                           {10, 38, 256}, {40, 149, 32}, {8, 128, 32}, {9, 129, 40}};
+                           {10, 38, 256}, {40, 149, 32}, {8, 128, 32}, {9, 129, 40}, {4, 64, 32}, {5, 65, 32}};
   for (const auto& im : images)
     if (check_image(im[0], im[1], im[2])) return 1;
-  return check_u_reads();
+  if (check_u_reads()) return 1;
+  return check_order(7, 20, 250, 4) || check_order(3, 10, 125, 8) || check_order(1, 1, 1, 2) || check_order(5, 17, 9, 1) ||
+         check_order(2, 80, 998, 1);
 }

@@ -20,17 +20,19 @@ for _ in range(3):
     ffi.check(lib.pa_conv3x3_wino4(ffi.ptr(X), B, H, W, cin, ffi.ptr(U), ffi.ptr(sh), None, ffi.ptr(Y), cin, 1,
                                    ffi.stream()), "wino4")
 torch.cuda.synchronize()
-buf = np.zeros(8 * 4 * 64 * 6, dtype=np.uint64)
+buf = np.zeros(8 * 4 * 64 * 10, dtype=np.uint64)
 lib.pa_wino4_read_stamps.argtypes = [C.c_void_p]
 assert lib.pa_wino4_read_stamps(buf.ctypes.data) == 0
-st = buf.reshape(8, 4, 64, 6).astype(np.int64)
+st = buf.reshape(8, 4, 64, 10).astype(np.int64)
 nst = cin // 8
 names = ["dma wait", "barrier", "setup+transform", "mfma run", "rest"]
 for wg in (0, 1):
     for wave in range(4):
-        d = np.diff(st[wg, wave], axis=1)                         # (64, 5)
+        d = np.diff(st[wg, wave, :, :6], axis=1)                  # (64, 5)
+        e = st[wg, wave, :, 6:10] - st[wg, wave, :, 4:5]           # epilogue marks relative to the end of the MFMA run
         full = st[wg, wave, 1:, 0] - st[wg, wave, :-1, 0]          # stage to stage
         last = (np.arange(64) % nst) == nst - 1
         print(f"wg {wg} wave {wave}: " + " | ".join(f"{n} {d[~last, i].mean():.0f}" for i, n in enumerate(names)) +
               f" || stage {full[~last[:-1]].mean():.0f} cycles; tile's last stage: rest (epilogue) {d[last, 4].mean():.0f}, "
-              f"next stage's dma wait {d[np.roll(last, 1), 0][1:].mean():.0f}")
+              f"next stage's dma wait {d[np.roll(last, 1), 0][1:].mean():.0f}; epilogue marks (cg0 columns, cg0 stores, "
+              f"cg1 columns, cg1 stores) {[int(x) for x in e[last].mean(axis=0)]}")
