@@ -50,6 +50,9 @@ namespace pa {
 #ifndef PA_W4_STAMP
 #define PA_W4_STAMP 0
 #endif
+#ifndef W4_ROWS_PER_REGION   // rows of the transform's second pass between two scheduling barriers (1, 2, 3 or 6)
+#define W4_ROWS_PER_REGION 1
+#endif
 #if PA_W4_STAMP
 // development instrumentation (never in the product build): s_memtime at the phases of the first 64 stages of
 // workgroups 0 .. 7, per wave; read back with pa_wino4_read_stamps
@@ -291,6 +294,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       }
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
+#ifdef PA_W4_NOTRANSFORM   // development A/B (timing only): no reads, no arithmetic
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[i][j] = f32x2{(float)lane, (float)(i + j)};
+      if (false)
+#endif
       {
         const unsigned char* pb = my_patch + pbase;
         f32x2 tt[6][6];
@@ -298,13 +308,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         // scheduler issues all 36 reads first and the 72 extra registers spill).  (Two columns between the barriers
         // were measured SLOWER: 2 745 instead of 1 700 cycles for setup + transform.)
         f32x2 x[2][6];
+#ifdef PA_W4_NOPATCHREAD   // development A/B (timing only): the arithmetic on register values, no LDS reads
+#define W4_RD(i, j) f32x2{(float)(lane + (i)), (float)(s + (j))}
+#else
+#define W4_RD(i, j) (*reinterpret_cast<const f32x2*>(pb + wino4_patch_k(i, j)))
+#endif
 #pragma unroll
-        for (int i = 0; i < 6; ++i) x[0][i] = *reinterpret_cast<const f32x2*>(pb + wino4_patch_k(i, 0));
+        for (int i = 0; i < 6; ++i) x[0][i] = W4_RD(i, 0);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           if (j + 1 < 6) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) x[(j + 1) & 1][i] = *reinterpret_cast<const f32x2*>(pb + wino4_patch_k(i, j + 1));
+            for (int i = 0; i < 6; ++i) x[(j + 1) & 1][i] = W4_RD(i, j + 1);
           }
           __builtin_amdgcn_sched_barrier(0);
           f32x2 y[6];
@@ -314,8 +329,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {   // rows: v[i][.] = B^T tt[i][.]
-          wino4_bt(tt[i], v[i], kc);
+        for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
+#pragma unroll
+          for (int r = 0; r < W4_ROWS_PER_REGION; ++r) wino4_bt(tt[i + r], v[i + r], kc);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
