@@ -50,6 +50,9 @@ namespace pa {
 #ifndef PA_W4_STAMP
 #define PA_W4_STAMP 0
 #endif
+#ifndef PA_W4_DMA_IN_TRANSFORM   // A/B: issue the next stage's staging between the transform's vector passes
+#define PA_W4_DMA_IN_TRANSFORM 0
+#endif
 #ifndef W4_ROWS_PER_REGION   // rows of the transform's second pass between two scheduling barriers (1, 2, 3 or 6)
 #define W4_ROWS_PER_REGION 1
 #endif
@@ -327,12 +330,28 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
           for (int i = 0; i < 6; ++i) tt[i][j] = y[i];
           __builtin_amdgcn_sched_barrier(0);
+#if PA_W4_DMA_IN_TRANSFORM
+          if (stage_next) {   // the 9 U pieces of the next stage, spread over the six columns
+            constexpr int first[7] = {0, 2, 3, 5, 6, 8, 9};
+#pragma unroll
+            for (int u = first[j]; u < first[j + 1]; ++u) wino4_piece(G::PINSTR + u, nst, pl, lane, slw);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
         }
 #pragma unroll
         for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
 #pragma unroll
           for (int r = 0; r < W4_ROWS_PER_REGION; ++r) wino4_bt(tt[i + r], v[i + r], kc);
           __builtin_amdgcn_sched_barrier(0);
+#if PA_W4_DMA_IN_TRANSFORM
+          if (stage_next) {   // the 13 patch pieces (this wave's patch has been read completely by now)
+            constexpr int pfirst[7] = {0, 3, 5, 7, 9, 11, 13};
+#pragma unroll
+            for (int u = pfirst[i]; u < pfirst[i + 1]; ++u) wino4_piece(u, nst, pl, lane, slw);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
         }
       }
 #if PA_W4_STAMP
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
                 for (int c2 = 0; c2 < 2; ++c2) uf[1][en][c2] = uf[0][en][c2];
             }
 #endif
-#ifndef PA_W4_NODMA     // (development A/B: no staging at all from inside the run)
+#if !defined(PA_W4_NODMA) && !PA_W4_DMA_IN_TRANSFORM   // (A/B: no staging from inside the run)
             if ((m == 4 || m == 6) && stage_next) {       // wave-uniform; pieces xp, xp + 1 of the next stage
               const int piece = xp + ((m - 4) >> 1);
               if (piece < W4_PIECES) wino4_piece(piece, nst, pl, lane, slw);

@@ -8,6 +8,8 @@ from pyannote_audio_amd import _build
 
 VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or None for the work tree)
     "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
+    "w4s_dmatr": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_DMA_IN_TRANSFORM=1", None),   # stamps, staging issued inside the transform
+    "w4dmatr": ("emb_winograd4.hip", "-DPA_W4_DMA_IN_TRANSFORM=1", None),
     "w4s_nopatch": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOPATCH=1", None),   # stamps, patch pieces out of bounds
     "w4s_notransform": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOTRANSFORM=1", None),
     "w4s_nopatchread": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOPATCHREAD=1", None),

@@ -8,7 +8,9 @@ import collections, csv, glob, json, sys
 
 # kernels that one launcher (= one profiler scope / bench.py roofline entry) dispatches between: folded into the
 # launcher's name, the per-kernel split kept under "_split"
-ALIASES = {"k_conv3x3_wino32": "k_conv3x3_wino", "k_linkage_centroid_mw": "k_linkage_centroid"}
+ALIASES = {"k_conv3x3_wino32": "k_conv3x3_wino", "k_linkage_centroid_mw": "k_linkage_centroid",
+           "k_linkage_fast": "k_linkage_centroid", "k_lf_square": "k_linkage_centroid",
+           "k_lf_row_nearest": "k_linkage_centroid"}
 
 def load(d, name):
     acc = collections.defaultdict(lambda: [0.0, set()])
