@@ -20,16 +20,19 @@ struct EmbPlan {
 inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 // Winograd F(4x4,3x3) (pa_conv3x3_wino4: units of 4 x 64 output pixels) or F(2x2,3x3) (pa_conv3x3_wino: 8 x 32,
-// 4 x 64 or 2 x 128 per workgroup) for an H x W map, both images being available: F(4x4) is 5-15 % faster per
-// USEFUL pixel on the 64 ... 256-channel layers (profiles/r4_wino4_anatomy.txt) but pads to whole units -- on the
-// narrow maps of short chunks (3 s: 149 / 75 / 38 columns) that can cost more than it gains.
-inline bool prefer_wino4(int H, int W) {
+// 4 x 64 or 2 x 128 per workgroup) for an H x W map, both weight images being available.  Per USEFUL pixel F(4x4) is
+// 1.02x / 1.12x / 1.29x as fast on the 64 / 128 / 256-channel layers (B = 512 launches on MI355X,
+// profiles/r4_wino4_anatomy.txt: 3.09 vs 3.14, 2.58 vs 2.88 ms at equal padding, 2.77 vs 2.98 ms with 20 % more
+// padding), but it pads to whole units -- on the narrow maps of short chunks (3 s: 149 / 75 / 38 columns) that can
+// cost more than it gains.
+inline bool prefer_wino4(int H, int W, int cin) {
   auto up = [](int a, int b) { return (long)((a + b - 1) / b) * b; };
   const long p4 = up(H, 4) * up(W, 64);
   long p2 = up(H, 8) * up(W, 32);
   if (up(H, 4) * up(W, 64) < p2) p2 = up(H, 4) * up(W, 64);
   if (up(H, 2) * up(W, 128) < p2) p2 = up(H, 2) * up(W, 128);
-  return p4 * 100 <= p2 * 108;
+  const long gain = cin >= 256 ? 125 : (cin >= 128 ? 110 : 102);   // percent
+  return p4 * 100 <= p2 * gain;
 }
 
 bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p) {
@@ -208,7 +211,7 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         RUN(pa_gather_s2(cur, B, H, W, cin, G, stream));
         RUN(pa_gemm_tn(G, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, B * Ho * Wo, cout, cin,
                        0, 0, stream));
-        if (w->blk_v2[blk] != nullptr && prefer_wino4(Ho, Wo))
+        if (w->blk_v2[blk] != nullptr && prefer_wino4(Ho, Wo, cout))
           RUN(pa_conv3x3_wino4(f1, B, Ho, Wo, cout, w->blk_v2[blk], w->blk_shift2[blk], R, cur, cout, 1,
                                stream));
         else if (w->blk_u2[blk] != nullptr)
@@ -222,7 +225,7 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
           pa::set_error("pa_emb_forward: block %d needs a shortcut conv but none was given", blk);
           return 3;
         }
-        if (w->blk_v1[blk] != nullptr && prefer_wino4(H, W))
+        if (w->blk_v1[blk] != nullptr && prefer_wino4(H, W, cin))
           RUN(pa_conv3x3_wino4(cur, B, H, W, cin, w->blk_v1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1,
                                stream));
         else if (w->blk_u1[blk] != nullptr)
@@ -231,7 +234,7 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         else
           RUN(pa_conv3x3(cur, B, H, W, cin, w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1, 1,
                          stream));
-        if (w->blk_v2[blk] != nullptr && prefer_wino4(H, W))
+        if (w->blk_v2[blk] != nullptr && prefer_wino4(H, W, cout))
           RUN(pa_conv3x3_wino4(f1, B, H, W, cout, w->blk_v2[blk], w->blk_shift2[blk], cur, f2, cout, 1,
                                stream));
         else if (w->blk_u2[blk] != nullptr)
