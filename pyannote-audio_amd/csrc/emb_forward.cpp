@@ -31,7 +31,10 @@ inline bool prefer_wino4(int H, int W, int cin) {
   long p2 = up(H, 8) * up(W, 32);
   if (up(H, 4) * up(W, 64) < p2) p2 = up(H, 4) * up(W, 64);
   if (up(H, 2) * up(W, 128) < p2) p2 = up(H, 2) * up(W, 128);
-  const long gain = cin >= 256 ? 125 : (cin >= 128 ? 110 : 102);   // percent
+  // percent.  Measured at 3 s (profiles/r4_emb3s_dispatch.json): F(2x2) everywhere 844.7 ms per 10 000 segments,
+  // F(4x4) on layer 4 only 815.9, on layers 2-4 799.8 -- F(4x4) also wins the 40 x 149 (1.20x the padded pixels)
+  // and 20 x 75 (1.11x) maps: the F(2x2) kernel does not reach its large-map rate on them either.
+  const long gain = cin >= 256 ? 130 : 122;
   return p4 * 100 <= p2 * gain;
 }
 
