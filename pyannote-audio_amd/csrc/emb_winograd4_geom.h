@@ -39,20 +39,21 @@ struct Wino4Unit {   // wave-uniform
 // class bits (emb_winograd_geom.h): top halo row, left halo column, every column at or right of the image border in
 // the LAST column group (F(4x4) mixes all six patch columns into every output of a tile: columns past the border
 // must be zeros, not the next row's pixels), padding lanes.
-__device__ __forceinline__ void wino4_patch_lanes(int* prel, int W, int CIN, int lane, int x0_last) {
+__device__ __forceinline__ int wino4_patch_lane(int piece, int W, int CIN, int lane, int x0_last) {
   using G = Wino4Geom;
+  const int row = 32 * piece + (lane >> 1);
+  const int pr = row / G::PWQ, idx = row % G::PWQ;   // pr = py*4 + residue
+  const int py = pr >> 2, px = 4 * idx + (pr & 3);
+  const bool real = piece < G::PINSTR && row < G::PROWS && px < G::PW;
+  int v = ((py * W + px) * CIN + 4 * (lane & 1)) * 4;
+  if (py == 0) v |= WCLS_TOP;
+  if (px == 0) v |= WCLS_LEFT;
+  if (x0_last - 1 + px >= W) v |= WCLS_RIGHT;
+  return real ? v : WCLS_PAD;
+}
+__device__ __forceinline__ void wino4_patch_lanes(int* prel, int W, int CIN, int lane, int x0_last) {
 #pragma unroll
-  for (int i = 0; i < G::PINSTR; ++i) {
-    const int row = 32 * i + (lane >> 1);
-    const int pr = row / G::PWQ, idx = row % G::PWQ;   // pr = py*4 + residue
-    const int py = pr >> 2, px = 4 * idx + (pr & 3);
-    const bool real = row < G::PROWS && px < G::PW;
-    int v = ((py * W + px) * CIN + 4 * (lane & 1)) * 4;
-    if (py == 0) v |= WCLS_TOP;
-    if (px == 0) v |= WCLS_LEFT;
-    if (x0_last - 1 + px >= W) v |= WCLS_RIGHT;
-    prel[i] = real ? v : WCLS_PAD;
-  }
+  for (int i = 0; i < Wino4Geom::PINSTR; ++i) prel[i] = wino4_patch_lane(i, W, CIN, lane, x0_last);
 }
 // class bits that stay SET for a unit (offset past num_records -> the DMA writes zeros)
 __device__ __forceinline__ int wino4_patch_keep(const Wino4Unit& u, int x0_last) {
