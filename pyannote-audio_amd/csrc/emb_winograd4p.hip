@@ -55,13 +55,12 @@ __device__ unsigned long long g_w4p_stamps[8 * 8 * 64 * 10];
 #endif
 
 struct Wino4pGeom {
-  static constexpr int EXCH_BYTES = 8192;   // per wave: 8 float4 per lane
   static constexpr int MAIL_OFF = Wino4Geom::LDS_BYTES;
   static constexpr int SPARE_OFF = MAIL_OFF + 16;
-  static constexpr int LDS_BYTES = SPARE_OFF + 4 * EXCH_BYTES;   // 159 760
-  static constexpr int POINTS = 18;                               // per wave
-  static constexpr int APOINTS = 16;                              // ... of them in AccVGPRs
-  static constexpr int SLOTS = 11;                                // LDS-DMA pieces per wave and stage
+  static constexpr int LDS_BYTES = SPARE_OFF + 8 * 2048;   // 143 376
+  static constexpr int POINTS = 18;                        // per wave
+  static constexpr int APOINTS = 16;                       // ... of them in AccVGPRs
+  static constexpr int SLOTS = 12;                         // LDS-DMA pieces per wave and stage (11 or 12 real ones)
 };
 
 template <bool HAS_R>
@@ -76,7 +75,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
   const int tid = threadIdx.x, lane = tid & 63;
   const int t = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pr = wv & 3, h = wv >> 2;   // pair = unit of the group; half = rows of the point grid
+  // waves w and w + 4 share a SIMD: group A = waves 0..3, group B = waves 4..7 run the same program ONE TICK apart
+  // (a tick = the stretch between two workgroup barriers: an input transform, an MFMA run or a quarter of the
+  // epilogue), so that on every SIMD one wave's MFMA run covers the other wave's transform / epilogue waits.
+  // A pair (two neighbouring waves of one group, on different SIMDs) owns one unit.
+  const int grp = wv >> 2, pr = wv >> 1, h = wv & 1;
   unsigned char* my_patch = smem4p + pr * G::PATCH_BYTES;
   unsigned char* ubufs = smem4p + 4 * G::PATCH_BYTES;
   int* mail = reinterpret_cast<int*>(smem4p + P::MAIL_OFF);
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
     if (tid == 0) tq_done(tq, gridDim.x);
     return;
   }
+  __syncthreads();   // (everybody has read the mail before thread 0 can write it again)
   const int x0_last = (cgroups - 1) * G::TW;
   // this wave's share of the pair's 13 patch pieces: h = 0 -> 0..5 and 12, h = 1 -> 6..11
   int pla[7];
@@ -101,18 +105,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
   // rows of the point grid this half owns, in the order (outer, lo, hi)
   const int ig0 = h ? 5 : 0, ig1 = h ? 3 : 1, ig2 = h ? 4 : 2;
   W4Const kc;
-  f32x2 kA, kB, nkB;   // first pass of the half: P = x4 + kA x2, Q = x3 + kA x1, lo = P + kB Q, hi = P - kB Q
   {
     const float p4 = w4_opaque(4.f), m4 = w4_opaque(-4.f), m5 = w4_opaque(-5.f), p2 = w4_opaque(2.f),
                 m2 = w4_opaque(-2.f), m1 = w4_opaque(-1.f);
     kc.p4 = f32x2{p4, p4}; kc.m4 = f32x2{m4, m4}; kc.m5 = f32x2{m5, m5};
     kc.p2 = f32x2{p2, p2}; kc.m2 = f32x2{m2, m2}; kc.m1 = f32x2{m1, m1};
-    auto uni = [](float x) {   // (a float select lands in a vector register; the constants must be scalar)
-      return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
-    };
-    const float a = w4_opaque(uni(h ? -1.f : -4.f)), b = w4_opaque(uni(h ? 2.f : 1.f)),
-                nb = w4_opaque(uni(h ? -2.f : -1.f));
-    kA = f32x2{a, a}; kB = f32x2{b, b}; nkB = f32x2{nb, nb};
   }
   const int nstages = CIN / G::CB;
 
@@ -123,29 +120,34 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
   Wino4Ctx cctx = wino4_ctx(X, H, W, CIN, cur, cur_n0, x0_last), nctx = cctx;
   int buf = 0;
 
-  // one of this wave's 11 staging pieces of a stage (SLOT is a compile-time constant at every call site):
-  //   slots 0..5: patch pieces 6 h + slot;  slot 6: patch piece 12 (h = 0) / U piece 4 (h = 1);
-  //   slots 7..10: U pieces slot - 7 (h = 0) / slot - 2 (h = 1).   U piece u of the pair = KB number pr + 4 u.
-  auto issue_piece = [&](const int SLOT, const Wino4Stage& st) {
-    if (SLOT < 6 || (SLOT == 6 && h == 0)) {
+  // One of this wave's staging pieces of a stage (SLOT is a compile-time constant at every call site):
+  //   slots 0..5: patch pieces 6 h + slot;   slot 6: patch piece 12 (h = 0 only);
+  //   slots 7..11: U pieces (1 KB each) number wv + 8 (slot - 7) of the slab's 36 (slot 11: waves 0..3 only).
+  auto issue_patch_piece = [&](const int SLOT, const Wino4Stage& st) {
+    if (SLOT < 6 || h == 0) {
       const int piece = SLOT < 6 ? 6 * h + SLOT : 12;
-#ifdef PA_W4_NOPATCH
-      const int off = pla[SLOT < 7 ? SLOT : 0] | WCLS_PAD;
-#else
       const int off = pla[SLOT < 7 ? SLOT : 0] & st.keep;
-#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.pbuf + 1024 * piece), 16, off, 0, 0, 0);
-    } else {
-      const int u = SLOT == 6 ? 4 : (h ? SLOT - 2 : SLOT - 7);
-      const int k = pr + 4 * u;
+    }
+  };
+  auto issue_u_piece = [&](const int SLOT, const Wino4Stage& st) {
+    const int k = wv + 8 * (SLOT - 7);
+    if (SLOT < 11 || wv < 4)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(st.usrd, (lds4_ptr_t)(st.ubuf + 1024 * k), 16, lane * 16,
                                                st.usoff + 1024 * k, 0, 0);
-    }
+  };
+  // end of a tick: this wave's staging has landed, its LDS accesses are done; then everybody's
+  auto sync_tick = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
   {
     const Wino4Stage st0 = wino4_stage(cctx, U, COUT, CIN, 0, my_patch, ubufs);
 #pragma unroll
-    for (int i = 0; i < P::SLOTS; ++i) issue_piece(i, st0);
+    for (int i = 0; i < 7; ++i) issue_patch_piece(i, st0);
+#pragma unroll
+    for (int i = 7; i < P::SLOTS; ++i) issue_u_piece(i, st0);
   }
   int claim = 0;
   if (tid == 0) claim = tq_claim_own(tq);
@@ -159,58 +161,49 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
   unsigned long long st_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int st_iter = 0;
 #endif
+  sync_tick();                 // the first stage's images have landed
+  if (grp == 1) sync_tick();   // group B: one tick behind
   while (true) {
     for (int s = 0; s < nstages; ++s) {
+      // ================= tick T(s): this half's three rows of V = B^T d B for the lane's tile and channel pair
       W4P_STAMP(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
-      W4P_STAMP(1);
-      if (s == nstages - 1 && tid == 0) mail[0] = tq_resolve(tq, claim);
-      wino4_barrier();   // A: ... everybody's; and everybody is done with the other U buffer
-      W4P_STAMP(2);
-      unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
-      unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
-      bool stage_next = true;
-      Wino4Stage nst;
-      if (s + 1 < nstages) {
-        nst = wino4_stage(cctx, U, COUT, CIN, s + 1, my_patch, uother);
-      } else {
-        nq = mail[0];
-        stage_next = nq >= 0;
-        wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups);
-        nxt = wino4_unit(wk.unit0 + pr, cgroups, trows, num_units);
-        nxt.valid &= wk.valid;
-        nxt_n0 = wk.n0;
-        nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
-        nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
-      }
-      // ---- this half's three rows of V = B^T d B for the lane's tile and channel pair
       f32x2 v[3][6];
       {
         const unsigned char* pb = my_patch + pbase;
-        const unsigned char* po = pb + h * wino4_patch_k(1, 0);   // the outer row reads patch rows {0, 2, 4} + h
         f32x2 tt[3][6];
-        f32x2 x[2][7];   // patch rows 1..4 of a column, then the outer row's three
-#define W4P_RD(c, j)                                                                                  \
-  ((c) < 4 ? *reinterpret_cast<const f32x2*>(pb + wino4_patch_k(1 + ((c) < 4 ? (c) : 0), j))          \
-           : *reinterpret_cast<const f32x2*>(po + wino4_patch_k(2 * ((c) >= 4 ? (c)-4 : 0), j)))
+        // first pass, per patch column j (5 reads, 6 operations), column j + 1 read while column j is combined:
+        //   h = 0 (rows 0, 1, 2 of B^T): x = d[0..4][j]:  4 x0 - 5 x2 + x4 | (x4 - 4 x2) +- (x3 - 4 x1)
+        //   h = 1 (rows 5, 3, 4):        x = d[1..5][j]:  4 x0 - 5 x2 + x4 | (x3 - x1) +- 2 (x2 - x0)
+        auto first_pass = [&](auto half) {
+          constexpr int HH = decltype(half)::value;
+          f32x2 x[2][5];
+#define W4P_RD(c, j) (*reinterpret_cast<const f32x2*>(pb + wino4_patch_k((c) + HH, j)))
 #pragma unroll
-        for (int c = 0; c < 7; ++c) x[0][c] = W4P_RD(c, 0);
+          for (int c = 0; c < 5; ++c) x[0][c] = W4P_RD(c, 0);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          if (j + 1 < 6) {
+          for (int j = 0; j < 6; ++j) {
+            if (j + 1 < 6) {
 #pragma unroll
-            for (int c = 0; c < 7; ++c) x[(j + 1) & 1][c] = W4P_RD(c, j + 1);
+              for (int c = 0; c < 5; ++c) x[(j + 1) & 1][c] = W4P_RD(c, j + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x2(&xx)[5] = x[j & 1];
+            tt[0][j] = w4fma(xx[0], kc.p4, w4fma(xx[2], kc.m5, xx[4]));
+            if (HH == 0) {
+              const f32x2 Pq = w4fma(xx[2], kc.m4, xx[4]), Qq = w4fma(xx[1], kc.m4, xx[3]);
+              tt[1][j] = Pq + Qq;
+              tt[2][j] = w4fma(Qq, kc.m1, Pq);
+            } else {
+              const f32x2 Pq = w4fma(xx[1], kc.m1, xx[3]), Qq = w4fma(xx[0], kc.m1, xx[2]);
+              tt[1][j] = w4fma(Qq, kc.p2, Pq);
+              tt[2][j] = w4fma(Qq, kc.m2, Pq);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          const f32x2(&xx)[7] = x[j & 1];   // xx[0..3] = d[1..4][j]; xx[4..6] = d[{0,2,4} + h][j]
-          const f32x2 Pq = w4fma(xx[1], kA, xx[3]);
-          const f32x2 Qq = w4fma(xx[0], kA, xx[2]);
-          tt[0][j] = w4fma(xx[4], kc.p4, w4fma(xx[5], kc.m5, xx[6]));
-          tt[1][j] = w4fma(Qq, kB, Pq);
-          tt[2][j] = w4fma(Qq, nkB, Pq);
-          __builtin_amdgcn_sched_barrier(0);
-        }
 #undef W4P_RD
+        };
+        if (h == 0) first_pass(std::integral_constant<int, 0>{});
+        else first_pass(std::integral_constant<int, 1>{});
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
           wino4_bt(tt[il], v[il], kc);
@@ -220,10 +213,32 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
 #if PA_W4P_STAMP
       asm volatile("s_nop 0" ::"v"(v[2][5]), "v"(v[0][0]));
 #endif
-      W4P_STAMP(3);
-      wino4_barrier();   // B: both halves have read the pair's patch; the next stage's may be staged over it
-      W4P_STAMP(4);
-      // ---- 18 points x 2 channel groups x 2 k-steps, two points at a time
+      // the claim of the NEXT group (issued at the start of this tile) is published by the barrier in front of
+      // group A's last MFMA run; group B reads it one tick later, nobody writes it again before the next tile's
+      if (s == nstages - 1 && tid == 0) mail[0] = tq_resolve(tq, claim);
+      W4P_STAMP(1);
+      sync_tick();
+      // ================= tick R(s): the MFMA run, with the staging of stage s + 1 issued from inside it
+      W4P_STAMP(2);
+      unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
+      unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
+      bool stage_u = true;                  // U of the next stage / of the next group's first stage
+      const bool stage_patch = s + 1 < nstages;   // (the next GROUP's first patch is staged in the last epilogue tick)
+      Wino4Stage nst;
+      if (s + 1 < nstages) {
+        nst = wino4_stage(cctx, U, COUT, CIN, s + 1, my_patch, uother);
+      } else {
+        nq = mail[0];
+        stage_u = nq >= 0;
+        wk = wino4_decode(stage_u ? nq : 0, n_tiles, num_groups);
+        nxt = wino4_unit(wk.unit0 + pr, cgroups, trows, num_units);
+        nxt.valid &= wk.valid;
+        nxt_n0 = wk.n0;
+        nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
+        nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
+      }
+      // 18 points x 2 channel groups x 2 k-steps, two points at a time (a dependent MFMA is four MFMAs behind its
+      // producer); U fragments of the next pair and one staging piece go behind individual MFMAs
       auto mfma_run = [&](auto first_stage) {
         constexpr bool FIRST = decltype(first_stage)::value;
         const unsigned char* ub[3] = {umine + ubase + 6 * 1024 * ig0, umine + ubase + 6 * 1024 * ig1,
@@ -258,27 +273,33 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
               for (int c2 = 0; c2 < 2; ++c2) uf[par ^ 1][en][c2] = W4P_U(xp + 2 + en, c2);
               __builtin_amdgcn_sched_barrier(0);
             }
-#ifndef PA_W4_NODMA
-            if ((m == 4 || m == 6) && stage_next) {   // wave-uniform
-              const int slot = xp + ((m - 4) >> 1);
-              if (slot < P::SLOTS) issue_piece(slot, nst);
+            if (m == 3 || m == 5 || m == 7) {   // staging slots 0 .. 11 behind the first four point pairs
+              const int slot = 3 * (xp >> 1) + ((m - 3) >> 1);
+              if (slot < 7) {
+                if (stage_patch) issue_patch_piece(slot < 7 ? slot : 0, nst);
+              } else if (slot < P::SLOTS) {
+                if (stage_u) issue_u_piece(slot >= 7 && slot < P::SLOTS ? slot : 7, nst);
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
-#endif
           }
         }
 #undef W4P_U
       };
       if (s == 0) mfma_run(std::true_type{});
       else mfma_run(std::false_type{});
-      W4P_STAMP(5);
       buf ^= 1;
+      W4P_STAMP(3);
+      sync_tick();
+      W4P_STAMP(4);
       if (s + 1 < nstages) W4P_STAMP_FLUSH();
     }
-    // ---- inverse transform: own rows along the columns, partial output rows, exchange, BN shift (+ residual)
-    // (+ ReLU), 16-byte stores of output rows 2 h, 2 h + 1
+    // ================= ticks E1 .. E4: inverse transform.  Own rows along the columns (r = M[row, :] A), partial
+    // output rows, two of them handed to the partner through LDS, BN shift (+ residual) (+ ReLU), 16-byte stores of
+    // output rows 2 h, 2 h + 1.  Exchange slot of a wave: 8 rows of 1 KB (one float4 per lane each); rows 0..5 lie in
+    // the half of the pair's patch block that the PARTNER stages (the partner is also the one who reads them: it
+    // stages the next group's patch over them behind its own last read), rows 6..7 in the spare space.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (the compiler cannot see them)
-    wino4_barrier();   // E: every wave is behind its last MFMA run: that stage's U slab is exchange space now
     {
       W4Const4 k4;
       {
@@ -288,9 +309,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
         k4.p4 = f32x4{p4, p4, p4, p4}; k4.p8 = f32x4{p8, p8, p8, p8};
         k4.m2 = f32x4{m2, m2, m2, m2}; k4.m8 = f32x4{m8, m8, m8, m8};
       }
-      unsigned char* ulast = ubufs + (buf ^ 1) * G::USLAB_BYTES;   // (buf was flipped behind the last run)
-      unsigned char* slot_mine = (h ? ulast : spare) + pr * P::EXCH_BYTES + lane * 16;
-      const unsigned char* slot_peer = (h ? spare : ulast) + pr * P::EXCH_BYTES + lane * 16;
+      unsigned char* mine_lo = my_patch + (1 - h) * 6144 + lane * 16;        // rows 0..5 of this wave's slot
+      unsigned char* mine_hi = spare + wv * 2048 + lane * 16 - 6 * 1024;     // rows 6..7
+      const unsigned char* peer_lo = my_patch + h * 6144 + lane * 16;
+      const unsigned char* peer_hi = spare + (wv ^ 1) * 2048 + lane * 16 - 6 * 1024;
+#define W4P_MINE(row) (*reinterpret_cast<f32x4*>(((row) < 6 ? mine_lo : mine_hi) + 1024 * (row)))
+#define W4P_PEER(row) (*reinterpret_cast<const f32x4*>(((row) < 6 ? peer_lo : peer_hi) + 1024 * (row)))
       const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
           Y + (long)cur.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
                                     : accv[(l) >= P::APOINTS ? (l)-P::APOINTS : 0][cg])
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
+        // ---- tick E1 / E3: partials of channel group cg
         f32x4 sh;   // BN shift of this lane's four channels, through the scalar cache (see emb_winograd4.hip)
         {
           const float* sp = shift + cur_n0 + 16 * cg;
@@ -318,8 +343,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
           for (int r = 0; r < 4; ++r)
             sh[r] = g == 0 ? s16[r] : (g == 1 ? s16[4 + r] : (g == 2 ? s16[8 + r] : s16[12 + r]));
         }
-        // r[il][q] = sum_j M[row il][j] A[j][q]
-        f32x4 r[3][4];
+        f32x4 r[3][4];   // r[il][q] = sum_j M[row il][j] A[j][q]
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
           // (the empty volatile asm re-defines each accumulator HERE: see emb_winograd4.hip)
@@ -348,12 +372,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
             own[1][qq] = w4fma4(df, k4.p8, r[0][qq]);
             send1 = df + df;
           }
-          *reinterpret_cast<f32x4*>(slot_mine + 1024 * qq) = sm;
-          *reinterpret_cast<f32x4*>(slot_mine + 1024 * (4 + qq)) = send1;
+          W4P_MINE(qq) = sm;
+          W4P_MINE(4 + qq) = send1;
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 rv[2][4];
-        if (HAS_R) {   // their latency hides under the exchange
+        if (HAS_R) {   // their latency hides under the tick change
 #pragma unroll
           for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -362,16 +386,33 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
                   f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                              rsrd, offq[qq] == OOB ? OOB : offq[qq] + k * srow + 64 * cg, 0, 0));
         }
-        wino4_barrier();   // X: the partner's partials are in LDS
+#if PA_W4P_STAMP
+        st_[5 + 2 * cg] = __builtin_amdgcn_s_memtime();
+#endif
+        sync_tick();
+        // ---- tick E2 / E4: the partner's partials, finish, store
 #if PA_W4P_STAMP
         st_[6 + 2 * cg] = __builtin_amdgcn_s_memtime();
 #endif
+        f32x4 got[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) got[k][qq] = W4P_PEER(4 * k + qq);
+        if (cg == 1 && nq >= 0) {
+          // the next group's first patch, over the rows just read (this wave's share of the pieces = exactly the
+          // rows it reads its partner's partials from, + piece 12 which no slot touches)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const Wino4Stage st0 = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, ubufs);
+#pragma unroll
+          for (int i = 0; i < 7; ++i) issue_patch_piece(i, st0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 got = *reinterpret_cast<const f32x4*>(slot_peer + 1024 * (4 * k + qq));
-            own[k][qq] = own[k][qq] + got + sh;
+            own[k][qq] = own[k][qq] + got[k][qq] + sh;
             if (HAS_R) own[k][qq] = own[k][qq] + rv[k][qq];
             own[k][qq] = __builtin_elementwise_max(own[k][qq], lo4);
           }
@@ -383,13 +424,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, own[k][qq]), ysrd,
                                                    offq[qq] == OOB ? OOB : offq[qq] + k * srow + 64 * cg, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (cg == 0) wino4_barrier();   // the partner has read: the slot is free for the second channel group
 #if PA_W4P_STAMP
-        st_[7 + 2 * cg] = __builtin_amdgcn_s_memtime();
+        if (cg == 1) st_[9] = __builtin_amdgcn_s_memtime();
 #endif
+        sync_tick();
       }
-    }
 #undef W4P_ACC
+#undef W4P_MINE
+#undef W4P_PEER
+    }
     W4P_STAMP_FLUSH();
     if (nq < 0) break;
     cur = nxt;
@@ -397,6 +440,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4p(
     cctx = nctx;
     if (tid == 0) claim = tq_claim_own(tq);
   }
+  if (grp == 0) sync_tick();   // group A's last tick (group B is one behind)
   if (tid == 0) tq_done(tq, gridDim.x);
 }
 

@@ -1,7 +1,7 @@
 """Phase anatomy of k_conv3x3_wino4p (development aid): runs one layer shape with the instrumented library
 (tools/build_variants.py: libpa_w4pstamp.so) and prints, per wave of workgroup 0, the mean cycles of a stage spent
-in: wait for the stage's DMA | barrier A | setup + input transform | barrier B | MFMA run (with the interleaved DMA
-issue); and for a tile's last stage the epilogue marks.
+in the ticks: input transform | sync | MFMA run (with the interleaved DMA issue) | sync; and for a tile's last
+stage the epilogue marks.
 usage: PA_LIB=pyannote-audio_amd/build/variants/libpa_w4pstamp.so python tools/wino4p_stamps.py [cin H W B]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,14 +25,13 @@ lib.pa_wino4p_read_stamps.argtypes = [C.c_void_p]
 assert lib.pa_wino4p_read_stamps(buf.ctypes.data) == 0
 st = buf.reshape(8, 8, 64, 10).astype(np.int64)
 nst = cin // 8
-names = ["dma wait", "barrier A", "setup+transform", "barrier B", "mfma run"]
+names = ["transform", "sync", "mfma run", "sync"]
 for wg in (0, 1):
     for wave in range(8):
-        d = np.diff(st[wg, wave, :, :6], axis=1)                  # (64, 5)
-        e = st[wg, wave, :, 6:10] - st[wg, wave, :, 5:6]           # epilogue marks relative to the end of the MFMA run
+        d = np.diff(st[wg, wave, :, :5], axis=1)                  # (64, 4)
+        e = st[wg, wave, :, 5:10] - st[wg, wave, :, 4:5]           # epilogue marks relative to the tick behind the last run
         full = st[wg, wave, 1:, 0] - st[wg, wave, :-1, 0]          # stage to stage
         last = (np.arange(64) % nst) == nst - 1
         print(f"wg {wg} wave {wave}: " + " | ".join(f"{n} {d[~last, i].mean():.0f}" for i, n in enumerate(names)) +
               f" || stage {full[~last[:-1]].mean():.0f} cycles; tile's last stage to next tile {full[last[:-1]].mean():.0f}; "
-              f"epilogue marks after the last run (cg0 exchanged, cg0 stored, cg1 exchanged, cg1 stored) "
-              f"{[int(x) for x in e[last].mean(axis=0)]}")
+              f"epilogue marks (E1 done, E2 starts, E3 done, E4 starts, E4 done) {[int(x) for x in e[last].mean(axis=0)]}")
