@@ -204,11 +204,6 @@ int pa_winograd4_pack_host(const float* conv_weight /* (cout, cin, 3, 3), resnet
                            float* U_slabs /* HOST buffer, 36 * cout * cin floats */);
 int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                      const float* R, float* Y, int cout, int relu, void* stream);
-/* ... with the kernel named: 0 = one wave per SIMD owns a unit of 16 tiles x 32 output channels x all 36 points
- * (csrc/emb_winograd4.hip), 1 = two waves per SIMD, the 36 points split between a pair of waves
- * (csrc/emb_winograd4p.hip).  pa_conv3x3_wino4 runs the one PA_WINO4_PAIRED selects. */
-int pa_conv3x3_wino4_kernel(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
-                            const float* R, float* Y, int cout, int relu, int kernel, void* stream);
 int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream);
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream);

@@ -41,15 +41,129 @@
 
 #include <type_traits>
 
-#include "emb_winograd4_dev.h"
+#include "common.h"
+#include "emb_winograd_geom.h"
+#include "emb_winograd4_geom.h"
 
 namespace pa {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds4_ptr_t;
+
+__device__ __forceinline__ void wino4_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// ---- B^T x for a 6-vector of channel pairs (12 packed operations)
+//   y0 = 4 x0 - 5 x2 + x4          y1 = (x4 - 4 x2) + (x3 - 4 x1)      y2 = (x4 - 4 x2) - (x3 - 4 x1)
+//   y5 = 4 x1 - 5 x3 + x5          y3 = (x4 - x2) + 2 (x3 - x1)        y4 = (x4 - x2) - 2 (x3 - x1)
+struct W4Const {
+  f32x2 p4, m4, m5, p2, m2, m1;
+};
+__device__ __forceinline__ f32x2 w4fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void wino4_bt(const f32x2 (&x)[6], f32x2 (&y)[6], const W4Const& k) {
+  const f32x2 a = w4fma(x[2], k.m4, x[4]);
+  const f32x2 b = w4fma(x[1], k.m4, x[3]);
+  const f32x2 c = w4fma(x[2], k.m1, x[4]);
+  const f32x2 d = w4fma(x[1], k.m1, x[3]);
+  y[0] = w4fma(x[0], k.p4, w4fma(x[2], k.m5, x[4]));
+  y[1] = a + b;
+  y[2] = w4fma(b, k.m1, a);
+  y[3] = w4fma(d, k.p2, c);
+  y[4] = w4fma(d, k.m2, c);
+  y[5] = w4fma(x[1], k.p4, w4fma(x[3], k.m5, x[5]));
+}
+
+// ---- A^T m for a 6-vector of float4 (four consecutive output channels): 4 outputs
+//   y0 = m0 + (m1 + m2) + (m3 + m4)     y1 = (m1 - m2) + 2 (m3 - m4)
+//   y2 = (m1 + m2) + 4 (m3 + m4)        y3 = (m1 - m2) + 8 (m3 - m4) + m5
+struct W4Const4 {
+  f32x4 m1, p2, p4, p8, m2, m8;
+};
+__device__ __forceinline__ f32x4 w4fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void wino4_at(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3,
+                                         const f32x4 m4, const f32x4 m5, f32x4 (&y)[4], const W4Const4& k) {
+  const f32x4 s1 = m1 + m2, d1 = w4fma4(m2, k.m1, m1), s2 = m3 + m4, d2 = w4fma4(m4, k.m1, m3);
+  y[0] = m0 + s1 + s2;
+  y[1] = w4fma4(d2, k.p2, d1);
+  y[2] = w4fma4(s2, k.p4, s1);
+  y[3] = w4fma4(d2, k.p8, d1) + m5;
+}
+
+// v_mfma_f32_16x16x4_f32 with the accumulator pinned to a register class ("a": AccVGPRs, "v": architectural)
+#define W4_MFMA_A(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define W4_MFMA_A_ZERO(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b))
+#define W4_MFMA_V(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define W4_MFMA_V_ZERO(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
+
+// opaque constants in SCALAR registers (a literal would be folded into unpacked single-lane arithmetic, a vector
+// register per constant is what made the epilogue spill: 28 registers of splats)
+__device__ __forceinline__ float w4_opaque(float v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// One stage's staging = 20 LDS-DMA pieces of 1 KB per wave (11 of the patch, 9 of the U slab).  A wave's DMA
+// instruction costs it 150-200 cycles of issue on its own (tools/probes/dma_probe.py) but 5-25 inside its own MFMA
+// run (interleave_probe.py) -- and with one wave per SIMD nobody else fills those cycles (first build of this kernel:
+// all 20 in front of the transform, 14.8 k cycles per stage instead of the 6.5 k its instructions add up to,
+// profiles/r4_wino4_v1_dma_exposed.txt).  So the pieces of stage s + 1 are issued from INSIDE the MFMA run of stage
+// s, two behind each of its first ten point pairs; the rest of the run hides their flight.
+struct Wino4Stage {       // wave-uniform
+  __amdgpu_buffer_rsrc_t xsrd, usrd;
+  int keep, usoff;
+  unsigned char* pbuf;    // this wave's patch block
+  unsigned char* ubuf;    // the U buffer being filled
+};
+// per (unit, cout slice): everything of a stage's staging that does not depend on the stage (computed once per tile;
+// the stage adds 32 bytes to the patch origin and one slab to the U offset)
+struct Wino4Ctx {
+  const float* xp;   // patch origin of stage 0
+  int xnum;          // bytes from there to the end of the image
+  int keep, usoff;
+};
+__device__ __forceinline__ Wino4Ctx wino4_ctx(const float* __restrict__ X, int H, int W, int CIN, const Wino4Unit& u,
+                                              int n0, int x0_last) {
+  using G = Wino4Geom;
+  const long img = (long)H * W * CIN;
+  const long org = ((long)(u.y0 - 1) * W + (u.x0 - 1)) * CIN;
+  Wino4Ctx c;
+  c.xp = X + (long)u.b * img + org;
+  c.xnum = (int)((img - org) * 4);
+  c.keep = wino4_patch_keep(u, x0_last);
+  c.usoff = (n0 / W_BN) * (CIN / G::CB) * G::USLAB_BYTES;
+#ifdef PA_W4_NOPATCH   // development A/B (never in the product build): every patch lane out of bounds -> no traffic
+  c.keep = -1;
+#endif
+  return c;
+}
+__device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float* __restrict__ U, int COUT, int CIN,
+                                                  int s, unsigned char* pbuf, unsigned char* ubuf) {
+  using G = Wino4Geom;
+  Wino4Stage st;
+  st.xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.xp + s * G::CB), 0, c.xnum - s * G::CB * 4,
+                                              0x00020000);
+  st.usrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 36 * COUT * CIN * 4, 0x00020000);
+  st.keep = c.keep;
+  st.usoff = c.usoff + s * G::USLAB_BYTES;
+#ifdef PA_W4_NOU       // ... every U piece from slab 0 (L2-resident)
+  st.usoff = 0;
+#endif
+  st.pbuf = pbuf;
+  st.ubuf = ubuf;
+  return st;
+}
 
 #ifndef PA_W4_STAMP
 #define PA_W4_STAMP 0
 #endif
 #ifndef PA_W4_DMA_IN_TRANSFORM   // A/B: issue the next stage's staging between the transform's vector passes
 #define PA_W4_DMA_IN_TRANSFORM 0
+#endif
+#ifndef PA_W4_ASM_DMA   // staging pieces inside the MFMA run as inline assembly with scalar-only set-up
+#define PA_W4_ASM_DMA 1
 #endif
 #ifndef W4_ROWS_PER_REGION   // rows of the transform's second pass between two scheduling barriers (1, 2, 3 or 6)
 #define W4_ROWS_PER_REGION 1
@@ -70,10 +184,6 @@ __device__ unsigned long long g_w4_stamps[8 * 4 * 64 * 10];
 #else
 #define W4_STAMP(p)
 #define W4_STAMP_FLUSH()
-#endif
-
-#ifndef PA_WINO4_PAIRED_DEFAULT   // which kernel pa_conv3x3_wino4 runs when PA_WINO4_PAIRED is not set
-#define PA_WINO4_PAIRED_DEFAULT 0
 #endif
 
 constexpr int W4_AGPR_POINTS = 32;   // 256 AccVGPRs; 4 points (32 registers) stay architectural
@@ -97,6 +207,48 @@ __device__ __forceinline__ void wino4_piece(const int I, const Wino4Stage& st, c
     const int k = slw + 4 * (I - G::PINSTR);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.usrd, (lds4_ptr_t)(st.ubuf + 1024 * k), 16, lane * 16,
                                              st.usoff + 1024 * k, 0, 0);
+  }
+}
+// The same piece from INSIDE the MFMA run, as inline assembly with scalar-only set-up: M0 and the scalar offset are
+// base + immediate (the compiler's version kept 22 precomputed LDS addresses in SGPRs, spilled them to VGPR lanes and
+// reloaded each with a v_readlane, and masked the patch offset with a v_and per piece: two vector-ALU instructions per
+// piece that queue behind the MFMA in flight -- the f32 MFMA runs on the vector ALUs -- and, issue being in order,
+// hold back the next MFMA: ~58 cycles per piece, profiles/r4_wino4_anatomy.txt).  `plm` = the patch offsets already
+// masked with the unit's class bits; `lane16` = lane * 16.
+struct Wino4Dma {           // wave-uniform LDS byte addresses
+  unsigned patch_lds;       // this wave's patch block
+  unsigned u_lds;           // the U buffer being filled + 1024 * wave
+  int usoff;                // slab offset of the stage + 1024 * wave
+};
+__device__ __forceinline__ unsigned w4_lds_addr(const void* p) {
+  return (unsigned)(size_t)(lds4_ptr_t)const_cast<void*>(p);
+}
+template <int I>
+__device__ __forceinline__ void wino4_piece_asm(const Wino4Stage& st, const Wino4Dma& d, const int (&plm)[13],
+                                                int lane16) {
+  using G = Wino4Geom;
+  if constexpr (I < G::PINSTR) {
+    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds"
+                 :: "s"(d.patch_lds), "i"(1024 * I), "v"(plm[I]), "s"(st.xsrd)
+                 : "memory");
+  } else {
+    int tmp;
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_add_u32 %0, %3, %2\n\tbuffer_load_dwordx4 %4, %5, %0 offen lds"
+                 : "=&s"(tmp)
+                 : "s"(d.u_lds), "i"(4096 * (I - G::PINSTR)), "s"(d.usoff), "v"(lane16), "s"(st.usrd)
+                 : "memory");
+  }
+}
+// (the piece number is a constant after unrolling: the switch folds)
+__device__ __forceinline__ void wino4_piece_asm_n(const int piece, const Wino4Stage& st, const Wino4Dma& d,
+                                                  const int (&plm)[13], int lane16) {
+  switch (piece) {
+#define W4_CASE(I) case I: wino4_piece_asm<I>(st, d, plm, lane16); break;
+    W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(9)
+    W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(15) W4_CASE(16) W4_CASE(17) W4_CASE(18)
+    W4_CASE(19) W4_CASE(20) W4_CASE(21)
+#undef W4_CASE
+    default: break;
   }
 }
 __device__ __forceinline__ void wino4_issue_all(const Wino4Stage& st, const Wino4Lanes& pl, int lane, int slw) {
@@ -132,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   wino4_patch_lanes(pl.a, W, CIN, lane, x0_last);
   const int pbase = wino4_patch_base(t, g);
   const int ubase = wino4_u_base(t, g);
+  const int lane16 = lane * 16;
   W4Const kc;
   {
     const float p4 = w4_opaque(4.f), m4 = w4_opaque(-4.f), m5 = w4_opaque(-5.f), p2 = w4_opaque(2.f),
@@ -257,6 +410,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // its producer); U fragments of the next pair are read while this pair's MFMAs issue.  The MFMAs are inline
       // assembly because the accumulators must be PINNED: 32 points in the 256 AccVGPRs, 4 in architectural
       // registers (left to the register allocator, 288 accumulators + the transform spill ~200 registers).
+#if PA_W4_ASM_DMA
+      int plm[G::PINSTR];
+#pragma unroll
+      for (int i = 0; i < G::PINSTR; ++i) plm[i] = pl.a[i] & nst.keep;
+      const Wino4Dma dma{w4_lds_addr(my_patch), w4_lds_addr(uother) + 1024u * slw, nst.usoff + 1024 * slw};
+#endif
       auto mfma_run = [&](auto first_stage) {
         constexpr bool FIRST = decltype(first_stage)::value;
         const unsigned char* ub = umine + ubase;
@@ -305,7 +464,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #if !defined(PA_W4_NODMA) && !PA_W4_DMA_IN_TRANSFORM   // (A/B: no staging from inside the run)
             if ((m == 4 || m == 6) && stage_next) {       // wave-uniform; pieces xp, xp + 1 of the next stage
               const int piece = xp + ((m - 4) >> 1);
+#if PA_W4_ASM_DMA
+              if (piece < W4_PIECES) wino4_piece_asm_n(piece, nst, dma, plm, lane16);
+#else
               if (piece < W4_PIECES) wino4_piece(piece, nst, pl, lane, slw);
+#endif
               __builtin_amdgcn_sched_barrier(0);
             }
 #endif
@@ -505,9 +668,6 @@ static int launch_wino4(const float* X, int B, int H, int W, int CIN, const floa
   return 0;
 }
 
-int conv3x3_wino4_paired(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
-                         const float* R, float* Y, int cout, int relu, hipStream_t st);   // emb_winograd4p.hip
-
 }  // namespace pa
 
 extern "C" {
@@ -525,36 +685,22 @@ int pa_wino4_read_stamps(unsigned long long* host) {
 // conv3x3, stride 1, pad 1, via Winograd F(4x4,3x3): Y = [relu](conv(X) + shift [+ R]).  X, R, Y: NHWC float32.
 // U: G g G^T (BatchNorm scale folded) in the slab layout of weights.winograd4_pack / pa_winograd4_pack_host:
 // [cout/32][cin/8][row = 32 xi + n][8], xi = 6a + b.
-// kernel: 0 = one wave per SIMD and unit (this file), 1 = two waves per SIMD, a unit's points split between a pair
-// of waves (emb_winograd4p.hip).
-int pa_conv3x3_wino4_kernel(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
-                            const float* R, float* Y, int cout, int relu, int kernel, void* stream) {
+int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                     const float* R, float* Y, int cout, int relu, void* stream) {
   if (B <= 0) return 0;
   PA_REQUIRE(cin % 8 == 0 && cin >= 32 && cout % pa::W_BN == 0,
              "pa_conv3x3_wino4: cin %% 8 == 0, cin >= 32 and cout %% 32 == 0 required");
   PA_REQUIRE((long)H * W * (cin > cout ? cin : cout) * 4 < (1L << 28),
              "pa_conv3x3_wino4: one image must be smaller than 256 MB");
-  PA_REQUIRE(kernel == 0 || kernel == 1, "pa_conv3x3_wino4_kernel: kernel must be 0 or 1");
   // `flops` = the direct convolution's (the reference's operation); the kernel executes 36/144 of them
   pa::ProfScope prof("k_conv3x3_wino4", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
                      4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
-  const int rc = kernel == 1 ? pa::conv3x3_wino4_paired(X, B, H, W, cin, U, shift, R, Y, cout, relu, st)
-                 : R != nullptr ? pa::launch_wino4<true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st)
-                                : pa::launch_wino4<false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  const int rc = R != nullptr ? pa::launch_wino4<true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st)
+                              : pa::launch_wino4<false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
   if (rc != 0) return rc;
   PA_CHECK_LAUNCH("pa_conv3x3_wino4");
   return 0;
-}
-
-// the product entry point: the kernel PA_WINO4_PAIRED selects (default below)
-int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
-                     const float* R, float* Y, int cout, int relu, void* stream) {
-  static const int kernel = [] {
-    const char* e = getenv("PA_WINO4_PAIRED");
-    return e != nullptr ? (atoi(e) != 0 ? 1 : 0) : PA_WINO4_PAIRED_DEFAULT;
-  }();
-  return pa_conv3x3_wino4_kernel(X, B, H, W, cin, U, shift, R, Y, cout, relu, kernel, stream);
 }
 
 }  // extern "C"

@@ -187,10 +187,8 @@ def test_conv3x3_winograd(gpu_device):
         assert north_star_ratio(f"wino3x3_{cin}_{cout}_{H}x{W}_B{B}", y.permute(0, 3, 1, 2), ref) <= 1.0
 
 
-@pytest.mark.parametrize("kernel", [0, 1], ids=["one_wave_per_unit", "paired_waves"])
-def test_conv3x3_winograd_f4(gpu_device, kernel):
-    """pa_conv3x3_wino4_kernel (Winograd F(4x4,3x3), fp32; both kernels: emb_winograd4.hip / emb_winograd4p.hip) vs
-    torch conv2d: all ResNet34 channel configurations, odd /
+def test_conv3x3_winograd_f4(gpu_device):
+    """pa_conv3x3_wino4 (Winograd F(4x4,3x3), fp32) vs torch conv2d: all ResNet34 channel configurations, odd /
     ragged extents (tiles, tile rows and whole waves outside the image), with and without residual, enough images
     for several tiles per workgroup.  Bound per convolution: |err| <= 1e-4 max |ref| (F(4x4)'s transforms cost a
     digit against F(2x2): 2-6e-5 of the maximum on unit-variance data, tools/probes/winograd_f4_numerics.py; the
@@ -215,9 +213,9 @@ def test_conv3x3_winograd_f4(gpu_device, kernel):
         rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device)
         shd = sh.to(gpu_device)
         y = torch.full((B, H, W, cout), float("nan"), device=gpu_device)
-        ffi.check(lib.pa_conv3x3_wino4_kernel(ffi.ptr(xd), B, H, W, cin, ffi.ptr(ud), ffi.ptr(shd),
-                                              ffi.ptr(rd) if use_res else None, ffi.ptr(y), cout, 1, kernel,
-                                              ffi.stream()), "conv3x3_wino4")
+        ffi.check(lib.pa_conv3x3_wino4(ffi.ptr(xd), B, H, W, cin, ffi.ptr(ud), ffi.ptr(shd),
+                                       ffi.ptr(rd) if use_res else None, ffi.ptr(y), cout, 1, ffi.stream()),
+                  "conv3x3_wino4")
         torch.cuda.synchronize()
         got = y.permute(0, 3, 1, 2).cpu()
         assert not torch.isnan(got).any(), (cin, cout, H, W, B)

@@ -7,7 +7,6 @@ sys.path.insert(0, ROOT)
 from pyannote_audio_amd import _build
 
 VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or None for the work tree)
-    "w4pstamp": ("emb_winograd4p.hip", "-DPA_W4P_STAMP=1", None),                # paired F(4x4) kernel: phase stamps (tools/wino4p_stamps.py)
     "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
     "w4s_dmatr": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_DMA_IN_TRANSFORM=1", None),   # stamps, staging issued inside the transform
     "w4dmatr": ("emb_winograd4.hip", "-DPA_W4_DMA_IN_TRANSFORM=1", None),
