@@ -217,6 +217,11 @@ def roofline_entry(name: str, r: dict) -> dict:
                     r["flops"] * EXECUTED_FLOP_FRACTION.get(name, 1.0) / launches / 1e9, 3),
                 "sustained_mfma_tflops": SUSTAINED_MFMA_F32_TFLOPS,
                 "frac_of_sustained": round(executed / SUSTAINED_MFMA_F32_TFLOPS, 4)}
+        if name == "k_conv3x3_wino4":
+            # F(4x4) issues 36/144 of the direct convolution's multiplies, F(2x2) 16/36: the same wall-clock rate
+            # expressed in the currency of the F(2x2) kernel it replaced (rounds 1-3 quoted that kernel's `frac`)
+            roof["f2x2_equivalent_frac"] = round(algorithmic * EXECUTED_FLOP_FRACTION["k_conv3x3_wino"]
+                                                 / PEAK_MFMA_F32_TFLOPS, 4)
     else:
         ach = r["bytes"] / r["ms"] / 1e6
         roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
