@@ -175,30 +175,48 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
     return q;
   };
   u32x4 rp[NP], rw[NW];
-  auto gload = [&](const Tile& q, int c0) {
-    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(Wg + (long)q.n0 * CIN), 0, (9 * COUT - q.n0) * CIN * 4, 0x00020000);
+  // Per-lane byte offsets of a tile's staging loads (halo / out-of-image / padding lanes out of bounds: the hardware
+  // bounds check writes the zeros).  They do not depend on the channel block -- that is the scalar offset of the load
+  // -- so they are computed once per TILE (the patch: two integer divisions and four compares per element) or once
+  // per KERNEL (the weight slab), not once per stage: ~150 vector-ALU instructions per stage that were paid in
+  // matrix time (the f32 MFMA shares the vector ALUs).  Stride 2 only: the stride-1 instantiations (fallback of the
+  // Winograd kernels, Bottleneck ResNets) sit at the register limit and keep computing them in place.
+  constexpr bool HOIST = S == 2;
+  struct Offs {
+    int p[NP];
+  };
+  int offw[NW];
+#pragma unroll
+  for (int e = 0; e < NW; ++e) {
+    const int i = tid + 256 * e;
+    const int c4 = i & 3, rn = i >> 2;  // rn = tap*BN + n
+    const int tap = rn / BN, n = rn % BN;
+    offw[e] = (NWF4 % 256 == 0 || i < NWF4) ? ((tap * COUT + n) * CIN + 4 * c4) * 4 : OOB;
+  }
+  auto tile_offsets = [&](const Tile& q, Offs& o) {
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
       const int i = tid + 256 * e;
       const int c4 = i & 3, pp = i >> 2;
       const int py = pp / G::PW, px = pp % G::PW;
       const int iy = q.y0 * S - 1 + py, ix = q.x0 * S - 1 + px;
-      const int off = ((NPF4 % 256 == 0 || i < NPF4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                          ? ((iy * W + ix) * CIN + 4 * c4) * 4
-                          : OOB;
-      rp[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, c0 * 4, 0);
+      o.p[e] = ((NPF4 % 256 == 0 || i < NPF4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                   ? ((iy * W + ix) * CIN + 4 * c4) * 4
+                   : OOB;
     }
+  };
+  auto gload = [&](const Tile& q, const Offs& o, int c0) {
+    const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X + (long)q.b * H * W * CIN), 0, H * W * CIN * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wg + (long)q.n0 * CIN), 0, (9 * COUT - q.n0) * CIN * 4, 0x00020000);
+    Offs here;
+    if (!HOIST) tile_offsets(q, here);
 #pragma unroll
-    for (int e = 0; e < NW; ++e) {
-      const int i = tid + 256 * e;
-      const int c4 = i & 3, rn = i >> 2;  // rn = tap*BN + n
-      const int tap = rn / BN, n = rn % BN;
-      const int off = (NWF4 % 256 == 0 || i < NWF4) ? ((tap * COUT + n) * CIN + 4 * c4) * 4 : OOB;
-      rw[e] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, c0 * 4, 0);
-    }
+    for (int e = 0; e < NP; ++e)
+      rp[e] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, HOIST ? o.p[e] : here.p[e], c0 * 4, 0);
+#pragma unroll
+    for (int e = 0; e < NW; ++e) rw[e] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, offw[e], c0 * 4, 0);
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -232,7 +250,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
     return;
   }
   Tile cur = decode(t);
-  gload(cur, 0);
+  Offs oc, on;
+  if (HOIST) tile_offsets(cur, oc);
+  on = oc;
+  gload(cur, oc, 0);
   for (;;) {
     int ahead = 0;
     if (tid == 0) ahead = tq_claim_own(tq);
@@ -253,10 +274,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
       __syncthreads();
       if (c0 == 0) {     // CIN >= 2 channel blocks: the next tile is known before the last stage
         tn = s_next;
-        if (tn >= 0) nxt = decode(tn);
+        if (tn >= 0) {
+          nxt = decode(tn);
+          if (HOIST) tile_offsets(nxt, on);
+        }
       }
-      if (c0 + CB < CIN) gload(cur, c0 + CB);
-      else if (tn >= 0) gload(nxt, 0);
+      if (c0 + CB < CIN) gload(cur, oc, c0 + CB);
+      else if (tn >= 0) gload(nxt, on, 0);
       // ---- 9 taps x 8 k-steps (dy stays a real loop: unrolling all 9 taps only buys register pressure).
       // Prefetching the fragments of tap+1 under the MFMAs of tap with a pinned schedule -- what the
       // Winograd kernel needs -- was measured neutral here (79.4 vs 79.5 ms per audio-hour): two
@@ -359,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
     }
     if (tn < 0) break;
     cur = nxt;
+    oc = on;
   }
   if (tid == 0) tq_done(tq, gridDim.x);
 }

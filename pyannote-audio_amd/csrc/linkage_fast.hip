@@ -290,8 +290,20 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
   int scan_x = -1;                 // row being repaired (LF_X_SCAN)
   lf_u32 scan_nx = 0;              // ... its size
   long long tc = __builtin_readcyclecounter();
+#ifdef PA_LF_STAMP   // development: where a round's cycles go (thread 0 of workgroup 0; printed at the end)
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = tc, rounds = 0;
+#define LF_PH(i)                                          \
+  do {                                                    \
+    const long long now_ = __builtin_readcyclecounter();  \
+    ph[i] += now_ - pt;                                   \
+    pt = now_;                                            \
+  } while (0)
+#else
+#define LF_PH(i)
+#endif
 
   while (true) {
+    LF_PH(7);
     if (xmode == LF_X_MAIN) y_excl = pend_y;
     // ================= A. this thread's two smallest own rows; in a scan exchange only the workgroup of the
     // repaired row has anything new to say
@@ -342,7 +354,9 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         exch[pe][wave].ib = pb_idx;
       }
     }
+    LF_PH(0);
     __syncthreads();
+    LF_PH(1);
     // ================= C. wave 0: workgroup result -> exchange -> candidate table -> pop
     if (wave == 0) {
       lf_u64 m;
@@ -369,6 +383,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         const int wb = lf_wave_argmin(ck, ci, &m);
         pbk = m; pbi = lf_rl(ci, wb);
       }
+      LF_PH(2);
       // -- exchange: this workgroup's record out, everybody's records in
       lf_u64 c_key = LF_INF;    // this lane's part of the records (lanes 4g: best, 4g+1: second, 4g+2: scan minimum)
       lf_u32 c_idx = 0xffffffffu, c_nb = NONE32, c_sz = 0;
@@ -439,6 +454,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
           c_key = pbk; c_idx = pbi;
         }
       }
+      LF_PH(3);
       // -- table update
       const int q = lane & 3;
       int ap_row = -1;
@@ -497,8 +513,13 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         o.action = action; o.fail = f; o.x = x; o.nbx = nbx; o.nx = nx; o.key = mk;
         o.ap_row = ap_row; o.ap_nbx = ap_nbx; o.ap_key = ap_key;
       }
+      LF_PH(4);
     }
     __syncthreads();
+    LF_PH(5);
+#ifdef PA_LF_STAMP
+    ++rounds;
+#endif
     const LfFinal F = fin[pe];
     // ================= D. the owner thread stores the bound that arrived with this exchange
     if (F.ap_row >= 0 && owner_wg(F.ap_row) == wg && tid == (F.ap_row & (LF_T - 1))) {
@@ -557,6 +578,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
       scan_nx = F.nx;
       xmode = LF_X_SCAN;
       ++st_rep;
+      LF_PH(6);
       continue;
     }
     // ================= E. merge x into y = neighbor[x]
@@ -666,6 +688,13 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
     if (k >= n - 1) break;
     xmode = LF_X_MAIN;
   }
+#ifdef PA_LF_STAMP
+  if (wg == 0 && tid == 0)
+    printf("lf stamps n=%d G=%d rounds %lld; cycles per round: A+B %lld | sync %lld | wg top-2 %lld | exchange %lld | "
+           "table+pop %lld | sync %lld | scan %lld (per repair) | merge pass etc. %lld (per merge)\n",
+           n, G, rounds, ph[0] / rounds, ph[1] / rounds, ph[2] / rounds, ph[3] / rounds, ph[4] / rounds,
+           ph[5] / rounds, ph[6] / (st_rep ? st_rep : 1), ph[7] / (k ? k : 1));
+#endif
   if (wg == 0 && tid == 0) {
     __hip_atomic_store(status, fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (stats != nullptr) {

@@ -8,7 +8,9 @@ problems stay in SciPy: the launch + copy overhead exceeds the work."""
 from __future__ import annotations
 
 import contextlib
+import os
 import threading
+import time
 
 import numpy as np
 import torch
@@ -93,15 +95,29 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     n = X.shape[0]
     ffi.require_gpu()
     lib = ffi.load()
+    global last_linkage_stats, last_linkage_phases
+    timed = os.environ.get("PA_LINKAGE_TIMING") == "1"   # development: where the wall time of a call goes
+    marks = [("start", time.perf_counter())]
+
+    def mark(name):
+        if timed:
+            torch.cuda.synchronize(device)
+            marks.append((name, time.perf_counter()))
+
     Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device)
     cond = torch.empty(n * (n - 1) // 2, dtype=torch.float64, device=device)
+    mark("upload + allocate condensed")
     ffi.check(lib.pa_pdist_f64(ffi.ptr(Xd), n, X.shape[1], ffi.ptr(cond), ffi.stream()), "pa_pdist_f64")
+    mark("pdist")
     Z = torch.empty((n - 1, 4), dtype=torch.float64, device=device)
     ws = torch.empty(lib.pa_linkage_workspace_bytes(n), dtype=torch.uint8, device=device)
+    mark("allocate workspace")
     ffi.check(lib.pa_linkage_centroid_f64_ex(ffi.ptr(cond), n, ffi.ptr(Z), ffi.ptr(ws), ws.numel(),
                                              1 if getattr(_hint, "alone", False) else 0, ffi.stream()),
               "pa_linkage_centroid_f64")
-    global last_linkage_stats
+    mark("merge kernels")
+    if timed:
+        last_linkage_phases = [(b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])]
     # development counters: [0:8] heap kernel (csrc/linkage.hip; all zero when the heap-free merge completed the
     # dendrogram), [8:16] heap-free merge (csrc/linkage_fast.hip): status (0 = complete, 1 = tie -> heap, 2 =
     # degenerate input -> heap, 3 = a workgroup
@@ -111,6 +127,7 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
 
 
 last_linkage_stats = None
+last_linkage_phases = None
 
 
 @ffi.on_device(lambda A, B, metric="cosine", device=None: device)
