@@ -50,6 +50,12 @@ namespace pa {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds4_ptr_t;
 
+// ds_read_b64 that stays one: volatile, so that the load/store optimizer does not fuse two of them into a
+// ds_read2_b64 (served in 16-lane groups on 32 banks: 4-way conflicts with these layouts), through an explicit LDS
+// pointer (a volatile access through a generic pointer is left a flat_load)
+typedef const volatile f32x2 __attribute__((address_space(3))) * w4_lds_f32x2_ptr;
+__device__ __forceinline__ f32x2 w4_lds_read64(const unsigned char* p) { return *(w4_lds_f32x2_ptr)p; }
+
 __device__ __forceinline__ void wino4_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   const int x0_last = (cgroups - 1) * G::TW;
   Wino4Lanes pl;
   wino4_patch_lanes(pl.a, W, CIN, lane, x0_last);
-  const int pbase = wino4_patch_base(t, g);
+  const int pbase0 = wino4_patch_base(t, g, 0), pbase1 = wino4_patch_base(t, g, 1);
   const int ubase = wino4_u_base(t, g);
   const int lane16 = lane * 16;
   W4Const kc;
@@ -353,7 +359,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       if (false)
 #endif
       {
-        const unsigned char* pb = my_patch + pbase;
+        const unsigned char* pb0 = my_patch + pbase0;
+        const unsigned char* pb1 = my_patch + pbase1;
         f32x2 tt[6][6];
         // columns of d: tt[.][j] = B^T d[.][j]; column j + 1 is read while column j is combined (left alone, the
         // scheduler issues all 36 reads first and the 72 extra registers spill).  (Two columns between the barriers
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #ifdef PA_W4_NOPATCHREAD   // development A/B (timing only): the arithmetic on register values, no LDS reads
 #define W4_RD(i, j) f32x2{(float)(lane + (i)), (float)(s + (j))}
 #else
-#define W4_RD(i, j) (*reinterpret_cast<const f32x2*>(pb + wino4_patch_k(i, j)))
+#define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + wino4_patch_k(i, j))
 #endif
 #pragma unroll
         for (int i = 0; i < 6; ++i) x[0][i] = W4_RD(i, 0);
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int cg = 0; cg < 2; ++cg) uf[0][e][cg] = *reinterpret_cast<const f32x2*>(ub + wino4_u_k(e, cg));
+          for (int cg = 0; cg < 2; ++cg) uf[0][e][cg] = w4_lds_read64(ub + wino4_u_k(e, cg));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xp = 0; xp < 36; xp += 2) {
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
               const int en = m >> 1;
 #pragma unroll
               for (int c2 = 0; c2 < 2; ++c2)
-                uf[par ^ 1][en][c2] = *reinterpret_cast<const f32x2*>(ub + wino4_u_k(xp + 2 + en, c2));
+                uf[par ^ 1][en][c2] = w4_lds_read64(ub + wino4_u_k(xp + 2 + en, c2));
               __builtin_amdgcn_sched_barrier(0);
             }
 #else

@@ -17,6 +17,14 @@ namespace pa {
 //          apart, read CONSECUTIVE rows: row = (py*4 + px%4)*17 + px/4;
 //   U slab (shared by the 4 waves, double-buffered) 36 points x 32 output channels x 8 input channels:
 //          row = 32 xi + n (32 B = the 8 input channels).
+// Bank swizzle.  Both images are read with ds_read_b64 by lane (t = lane & 15, g = lane >> 4) -- tile / output
+// channel t, channel pair g -- i.e. row r0 + t, pair g.  The hardware serves a ds_read_b64 in the lane groups {0-31}
+// and {32-63}, bank = (byte / 4) mod 64 (MI355X_MICROARCH.md, LDS table): with the pairs in their natural order the
+// 32 lanes (t, g in {0,1}) touch dwords 8 (r0 + t) + 2 g + {0,1}, rows 8 apart collide -- every read a 2-way
+// conflict (and the ds_read2_b64 the compiler fused pairs of them into, 16-lane groups mod 32 banks, 4-way: the
+// first PMC pass over this kernel counted 31 % of its cycles as LDS bank conflicts, profiles/r4_pipeline_pmc_sq.txt).
+// So rows whose index within their group of 16 / 17 has bit 3 set hold their two channel QUADS swapped: pair g sits
+// in slot g ^ 2.  Then the 32 lanes of a group cover dwords 8 t' + {0..3} (t' < 8) and 8 t' + {4..7}: 64 banks once.
 struct Wino4Geom {
   static constexpr int CB = 8;                       // input channels per stage
   static constexpr int TH = 4, TW = 64;              // output pixels per unit
@@ -39,13 +47,16 @@ struct Wino4Unit {   // wave-uniform
 // class bits (emb_winograd_geom.h): top halo row, left halo column, every column at or right of the image border in
 // the LAST column group (F(4x4) mixes all six patch columns into every output of a tile: columns past the border
 // must be zeros, not the next row's pixels), padding lanes.
+// rows that hold their channel quads swapped: index within the row group (tile number + column group) has bit 3 set
+__device__ __forceinline__ int wino4_swz(int idx) { return (idx >> 3) & 1; }
 __device__ __forceinline__ int wino4_patch_lane(int piece, int W, int CIN, int lane, int x0_last) {
   using G = Wino4Geom;
   const int row = 32 * piece + (lane >> 1);
   const int pr = row / G::PWQ, idx = row % G::PWQ;   // pr = py*4 + residue
   const int py = pr >> 2, px = 4 * idx + (pr & 3);
   const bool real = piece < G::PINSTR && row < G::PROWS && px < G::PW;
-  int v = ((py * W + px) * CIN + 4 * (lane & 1)) * 4;
+  // (this lane fills the 16-byte half (lane & 1) of the row: the channel quad stored there, see the bank swizzle)
+  int v = ((py * W + px) * CIN + 4 * ((lane & 1) ^ wino4_swz(idx))) * 4;
   if (py == 0) v |= WCLS_TOP;
   if (px == 0) v |= WCLS_LEFT;
   if (x0_last - 1 + px >= W) v |= WCLS_RIGHT;
@@ -65,14 +76,17 @@ __device__ __forceinline__ int wino4_patch_keep(const Wino4Unit& u, int x0_last)
 }
 
 // Patch reads of the input transform: tile t, patch element (i, j), channel pair g: byte address (within the wave's
-// block) 32 t + 8 g + K_ij, K_ij = 32 ((4 i + (j & 3)) * 17 + (j >> 2)) (compile time: a ds_read_b64 immediate).
-// The 64 lanes of one read cover 512 contiguous bytes.
-__device__ __forceinline__ int wino4_patch_base(int t, int g) { return 32 * t + 8 * g; }
+// block) base(t, g, j >> 2) + K_ij, K_ij = 32 ((4 i + (j & 3)) * 17 + (j >> 2)) (compile time: a ds_read_b64
+// immediate); the row read is number t + (j >> 2) of its group, which decides the slot of pair g.
+__device__ __forceinline__ int wino4_patch_base(int t, int g, int jq) {
+  return 32 * t + 8 * (g ^ (2 * wino4_swz(t + jq)));
+}
 constexpr int wino4_patch_k(int i, int j) { return 32 * ((4 * i + (j & 3)) * Wino4Geom::PWQ + (j >> 2)); }
 
 // U reads of the MFMA A operand: lane (m = lane & 15, g = lane >> 4) reads the input-channel pair g of output
-// channel 16 cg + m at point xi: base 32 m + 8 g, offset 1024 xi + 512 cg.
-__device__ __forceinline__ int wino4_u_base(int m, int g) { return 32 * m + 8 * g; }
+// channel 16 cg + m at point xi: base 32 m + 8 (g ^ 2 swz(m)), offset 1024 xi + 512 cg (rows n with bit 3 of n set
+// hold their quads swapped: weights.winograd4_pack / pa_winograd4_pack_host write them that way).
+__device__ __forceinline__ int wino4_u_base(int m, int g) { return 32 * m + 8 * (g ^ (2 * wino4_swz(m))); }
 constexpr int wino4_u_k(int xi, int cg) { return 1024 * xi + 512 * cg; }
 
 // Unit u of an (B, H, W) map: column group fastest, then tile row, then image -- the 4 units of a workgroup are

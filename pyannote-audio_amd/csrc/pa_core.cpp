@@ -209,7 +209,9 @@ extern "C" int pa_winograd4_pack_host(const float* conv_weight, const float* bn_
           for (int p = 0; p < 3; ++p)
             for (int q = 0; q < 3; ++q) u += G[a][p] * g[p][q] * G[b][q];
           const size_t slab = ((size_t)(o / 32) * stages + i / 8) * 36 * 32 * 8;
-          U_slabs[slab + (size_t)(32 * (6 * a + b) + (o % 32)) * 8 + (i % 8)] = (float)u;
+          // rows with bit 3 of (o % 32) set hold their two channel quads swapped (LDS bank swizzle of the kernel)
+          const int pos = ((o % 32) >> 3) & 1 ? (i % 8) ^ 4 : i % 8;
+          U_slabs[slab + (size_t)(32 * (6 * a + b) + (o % 32)) * 8 + pos] = (float)u;
         }
     }
   return 0;

@@ -506,10 +506,15 @@ def winograd4_weights(cw: torch.Tensor) -> torch.Tensor:
 def winograd4_pack(U: torch.Tensor) -> torch.Tensor:
     """[36][cout][cin] -> the staging image of csrc/emb_winograd4.hip, [cout/32][cin/8][row = 32 xi + n][8]: one
     CONTIGUOUS 36-KB slab per (32-cout slice, 8-cin stage), so that its LDS-DMA is a linear stream and lane
-    (n & 15, g) of the MFMA's A operand reads the input-channel pair g of output channel n at byte 32 row + 8 g."""
+    (n & 15, g) of the MFMA's A operand reads the input-channel pair g of output channel n at byte
+    32 row + 8 (g ^ 2 s), s = bit 3 of n: rows 8..15 and 24..31 of a slice hold their two channel quads swapped, which
+    makes the 32 lanes of a ds_read_b64 lane group hit 64 different LDS banks (csrc/emb_winograd4_geom.h)."""
     _, cout, cin = U.shape
     assert cout % 32 == 0 and cin % 8 == 0
-    A = U.reshape(36, cout // 32, 32, cin // 8, 8).permute(1, 3, 0, 2, 4)
+    A = U.reshape(36, cout // 32, 32, cin // 8, 8).permute(1, 3, 0, 2, 4).contiguous()   # [slice][stage][xi][n][8]
+    swapped = torch.cat([A[..., 4:], A[..., :4]], dim=-1)
+    rows = ((torch.arange(32) >> 3) & 1).bool().view(1, 1, 1, 32, 1)
+    A = torch.where(rows, swapped, A)
     return A.reshape(cout // 32, cin // 8, 36 * 32, 8).contiguous()
 
 

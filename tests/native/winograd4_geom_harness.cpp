@@ -4,8 +4,10 @@
 // every read returns exactly the patch element (pixel, channel pair) the Winograd tile needs, zeros wherever the
 // pixel lies outside the image (F(4x4) mixes all six patch columns into every output of a tile, so EVERY column
 // past the border must be a zero, not only the first), that no read touches an LDS location the DMA did not write,
-// and that the 64 lanes of one read cover 512 contiguous bytes (bank-conflict free at two passes).  Same for the
-// U-slab reads; and the unit order hands out every (unit, cout slice) exactly once, the slices of a group of four
+// and that every ds_read_b64 is bank-conflict free under the hardware's rule (MI355X_MICROARCH.md, LDS table: lane
+// groups {0-31} and {32-63}, bank = (byte / 4) mod 64: the 64 dwords of a group must be 64 different banks -- "512
+// contiguous bytes per wave", the first version of this check, is NOT that rule and let a 2-way conflict through).
+// Same for the U-slab reads; and the unit order hands out every (unit, cout slice) exactly once, the slices of a group of four
 // units on one XCD.  Exit code 0 = all good.
 #include <cstdio>
 #include <cstdlib>
@@ -50,28 +52,28 @@ static int check_unit(int H, int W, int CIN, int y0, int x0, int x0_last, int c0
   }
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < 6; ++j) {
-      std::set<int> bytes;
-      int lo = 1 << 30, hi = 0;
+      std::set<int> banks[2];
       for (int lane = 0; lane < 64; ++lane) {
         const int t = lane & 15, g = lane >> 4;
-        const int addr = wino4_patch_base(t, g) + wino4_patch_k(i, j);
+        const int addr = wino4_patch_base(t, g, j >> 2) + wino4_patch_k(i, j);
         if (addr % 8 != 0 || addr / 16 >= (int)lds.size()) return printf("read outside the patch block\n"), 1;
-        lo = addr < lo ? addr : lo;
-        hi = addr > hi ? addr : hi;
-        bytes.insert(addr);
+        banks[lane >> 5].insert((addr / 4) % 64);
+        banks[lane >> 5].insert((addr / 4 + 1) % 64);
         const Cell& c = lds[addr / 16];
         const int iy = y0 - 1 + i, ix = x0 - 1 + 4 * t + j;
         if (c.kind == 0) return printf("read of an LDS location the DMA never wrote (i=%d j=%d lane=%d)\n", i, j, lane), 1;
         const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
         if (inside) {
-          // the 8-byte read takes channels 2g, 2g+1: quad g >> 1, second half of the slot when g is odd
+          // the 8-byte read takes channels 2g, 2g+1: quad g >> 1 (wherever the swizzle put it), second half of the
+          // 16-byte slot when g is odd
           if (c.kind != 2 || c.gpix != (long)iy * W + ix || c.quad != (g >> 1) || ((addr % 16) / 8) != (g & 1))
             return printf("unit (%d,%d) lane %d (i=%d,j=%d): wrong element\n", y0, x0, lane, i, j), 1;
         } else {
           if (c.kind != 1) return printf("element (%d,%d) outside the image is not a hardware zero\n", iy, ix), 1;
         }
       }
-      if (bytes.size() != 64 || hi - lo != 504) return printf("transform read (i=%d,j=%d) is not 512 contiguous bytes\n", i, j), 1;
+      if (banks[0].size() != 64 || banks[1].size() != 64)
+        return printf("transform read (i=%d,j=%d): bank conflict in a 32-lane group\n", i, j), 1;
     }
   return 0;
 }
@@ -95,16 +97,19 @@ static int check_image(int H, int W, int CIN) {
 static int check_u_reads() {
   for (int xi = 0; xi < 36; ++xi)
     for (int cg = 0; cg < 2; ++cg) {
-      std::set<int> seen;
+      std::set<int> banks[2];
       for (int lane = 0; lane < 64; ++lane) {
         const int m = lane & 15, g = lane >> 4;
         const int addr = wino4_u_base(m, g) + wino4_u_k(xi, cg);
-        // slab image: row = 32 xi + n (n = 16 cg + m), 8 input channels of 4 bytes; the pair g at byte 8 g
-        if (addr != ((32 * xi + 16 * cg + m) * 8 + 2 * g) * 4) return printf("U read address\n"), 1;
+        // slab image: row = 32 xi + n (n = 16 cg + m), 8 input channels of 4 bytes; the pair g in slot g, or g ^ 2
+        // in the rows with bit 3 of n set (weights.winograd4_pack writes them that way)
+        const int n = 16 * cg + m, slot = g ^ (2 * ((n >> 3) & 1));
+        if (addr != ((32 * xi + n) * 8 + 2 * slot) * 4) return printf("U read address\n"), 1;
         if (addr + 8 > Wino4Geom::USLAB_BYTES) return printf("U read outside the slab\n"), 1;
-        seen.insert(addr);
+        banks[lane >> 5].insert((addr / 4) % 64);
+        banks[lane >> 5].insert((addr / 4 + 1) % 64);
       }
-      if (seen.size() != 64 || *seen.rbegin() - *seen.begin() != 504) return printf("U read not contiguous\n"), 1;
+      if (banks[0].size() != 64 || banks[1].size() != 64) return printf("U read: bank conflict in a 32-lane group\n"), 1;
     }
   return 0;
 }

@@ -48,7 +48,9 @@ def test_kernel_arithmetic_replayed_on_the_host(H, W, cin, cout):
             for xi in range(36):
                 for ns in range(cout // 32):
                     for st in range(cin // 8):
-                        u = slabs[ns, st, 32 * xi:32 * xi + 32, :]                 # (32 cout, 8 cin): kernel's rows
+                        u = slabs[ns, st, 32 * xi:32 * xi + 32, :].copy()          # (32 cout, 8 cin): kernel's rows
+                        sw = ((np.arange(32) >> 3) & 1).astype(bool)                # ... quads swapped where bit 3 of n
+                        u[sw] = np.concatenate([u[sw, 4:], u[sw, :4]], axis=1)
                         M[xi, 32 * ns:32 * ns + 32] += u @ v[xi // 6, xi % 6, 8 * st:8 * st + 8]
             z = at(M.reshape(6, 6, cout))                                          # (4, 6, cout): over a
             y = at(z.transpose(1, 0, 2))                                           # (4 q, 4 p, cout): over b
