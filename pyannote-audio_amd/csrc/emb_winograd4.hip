@@ -171,6 +171,9 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 #ifndef PA_W4_ASM_DMA   // staging pieces inside the MFMA run as inline assembly with scalar-only set-up
 #define PA_W4_ASM_DMA 1
 #endif
+#ifndef PA_W4_DEFER_STORES   // stores of channel group 0 issued from inside the column arithmetic of group 1:
+#define PA_W4_DEFER_STORES 1 // 0 = never, 1 = instantiation without residual only, 2 = both (spills: slower)
+#endif
 #ifndef W4_ROWS_PER_REGION   // rows of the transform's second pass between two scheduling barriers (1, 2, 3 or 6)
 #define W4_ROWS_PER_REGION 1
 #endif
@@ -521,6 +524,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // between them: 180 registers, 70-100 spills, 17 k cycles per tile.)
 #define W4_ACC(xi) ((xi) < W4_AGPR_POINTS ? acca[(xi) < W4_AGPR_POINTS ? (xi) : 0][cg] \
                                           : accv[(xi) >= W4_AGPR_POINTS ? (xi)-W4_AGPR_POINTS : 0][cg])
+      // A 16-byte store of 16 scattered 64-byte segments holds its wave ~200 cycles (the write path's back-pressure,
+      // not issue work).  The 16 stores of channel group 0 are therefore HELD and issued one by one from inside the
+      // column arithmetic of channel group 1 (three behind each of its first four columns, two behind the last two),
+      // where those cycles are filled with vector work; group 1's own stores have nothing left to hide under.
+      constexpr bool DEFER = PA_W4_DEFER_STORES == 2 || (PA_W4_DEFER_STORES == 1 && !HAS_R);
+      f32x4 held[4][4];
+      auto store_held = [&](const int k) {   // (k: compile-time after unrolling)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, held[k >> 2][k & 3]), ysrd,
+                                               offq[k & 3] == OOB ? OOB : offq[k & 3] + (k >> 2) * srow, 0, 0);
+      };
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
         // BN shift of this lane's four channels, through the SCALAR cache (uniform address, lgkmcnt): a vector load
@@ -590,6 +603,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           }
           // (two columns between barriers: one column alone is a dependency chain a single wave cannot fill)
           if (b & 1) __builtin_amdgcn_sched_barrier(0);
+          if (DEFER && cg == 1) {
+            constexpr int first[7] = {0, 3, 6, 9, 12, 14, 16};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = first[b]; k < first[b + 1]; ++k) store_held(k);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if (HAS_R && b == 3) {
 #pragma unroll
             for (int p = 2; p < 4; ++p)
@@ -617,12 +637,19 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
             o[p][qq] = __builtin_elementwise_max(o[p][qq], lo4);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if (DEFER && cg == 0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+          for (int p = 0; p < 4; ++p)
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd,
-                                                   offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0);
+            for (int qq = 0; qq < 4; ++qq) held[p][qq] = o[p][qq];
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd,
+                                                     offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #if PA_W4_STAMP
         st_[7 + 2 * cg] = __builtin_amdgcn_s_memtime();
