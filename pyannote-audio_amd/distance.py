@@ -112,10 +112,19 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     Z = torch.empty((n - 1, 4), dtype=torch.float64, device=device)
     ws = torch.empty(lib.pa_linkage_workspace_bytes(n), dtype=torch.uint8, device=device)
     mark("allocate workspace")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if os.environ.get("PA_LINKAGE_EVENTS") == "1" else None
+    if ev:
+        ev[0].record()
     ffi.check(lib.pa_linkage_centroid_f64_ex(ffi.ptr(cond), n, ffi.ptr(Z), ffi.ptr(ws), ws.numel(),
                                              1 if getattr(_hint, "alone", False) else 0, ffi.stream()),
               "pa_linkage_centroid_f64")
+    if ev:
+        ev[1].record()
     mark("merge kernels")
+    if ev:   # development: device time of the merge kernels without changing what the host does around them
+        ev[1].synchronize()
+        last_linkage_phases = [("whole call", time.perf_counter() - marks[0][1]),
+                               ("merge kernels (events)", ev[0].elapsed_time(ev[1]) / 1e3)]
     if timed:
         last_linkage_phases = [(b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])]
     # development counters: [0:8] heap kernel (csrc/linkage.hip; all zero when the heap-free merge completed the

@@ -6,7 +6,7 @@ tag=${1:-r2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --sequential"
+CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --sequential"
 python tools/probes/pingpong_probe.py > $out/mfma_probe.txt 2>&1
 python tools/clock_trace.py > $out/clock_trace.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/bench_under_rocprof.json 2> $out/stats.err
