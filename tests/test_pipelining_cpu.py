@@ -85,3 +85,26 @@ def test_tail_exception_reaches_the_consumer_and_abandoned_generator_terminates(
     t0 = time.perf_counter()
     gen2.close()                                                  # consumer walks away
     assert time.perf_counter() - t0 < 5.0
+
+
+def test_a_gate_that_times_out_is_logged(caplog):
+    """the safety net of the gate must not act silently (the tail then runs beside the next item's first stage)"""
+    import logging
+    import threading
+    from pyannote_audio_amd.pipelining import pipelined
+    hold = threading.Event()
+
+    def front(item, release):
+        if item == 1:
+            hold.wait(timeout=2.0)   # the front of item 1 neither releases nor returns in time
+        return item
+
+    def tail(state, alone):
+        if state == 0:
+            hold.set()
+        return state * 10
+
+    with caplog.at_level(logging.WARNING, logger="pyannote_audio_amd.pipelining"):
+        out = list(pipelined([0, 1], front, tail, gate_timeout=0.05))
+    assert out == [(0, 0), (1, 10)]
+    assert any("not released within" in r.getMessage() for r in caplog.records)
