@@ -126,7 +126,10 @@ struct ConvGeom {
   static constexpr int TW = 32 * TWT;
   static constexpr int PH = (TH - 1) * S + 3;
   static constexpr int PW = (TW - 1) * S + 3;
-  static constexpr int PWH = TW + 1;  // entries per column parity (S == 2)
+  // entries per column parity (S == 2): TW + 1, padded to 4 mod 8 -- the staging ds_write_b128 of 8 neighbouring lanes
+  // writes two pixels of DIFFERENT parity planes, PWH * 20 floats apart: 16 mod 32 banks apart only then (33 entries:
+  // 20 banks apart, 4 banks shared -- the 2-way conflicts of profiles/r3_pipeline_pmc_sq.txt)
+  static constexpr int PWH = ((TW + 1 + 3) / 8) * 8 + 4;
   static constexpr int PATCH = S == 1 ? PH * PW * CLD : PH * 2 * PWH * CLD;
 };
 
