@@ -15,9 +15,10 @@
 //     accumulators live in the AccVGPRs, the transformed patch (72) and the transform's temporaries in the
 //     architectural ones.  On gfx950 the f32 MFMA executes on the vector ALUs, nothing co-issues with it and SIMD
 //     time is the SUM of the issue cycles of everything (profiles/r2_mfma_probe.txt), so a second wave per SIMD only
-//     ever hid WAITS -- here there are none left to hide: both LDS images are double-buffered and the DMA of stage
-//     s + 1 (the next tile's first stage behind a tile's last one) is issued right after the barrier that opens
-//     stage s; it has 6 500 cycles to land.
+//     ever hid WAITS -- here there are none left to hide: the staging of stage s + 1 (the next tile's first stage
+//     behind a tile's last one) is issued from inside the MFMA run of stage s and has the rest of it to land.  (A
+//     two-waves-per-SIMD variant with the points of a unit split between a pair of waves was built and measured
+//     twice in round 4: slower both times, tools/probes/emb_winograd4_paired.hip.txt.)
 //   * a wave owns a UNIT = 16 consecutive tiles of one tile row of one image (4 x 64 output pixels), a workgroup 4
 //     consecutive units x 32 output channels -- any rows of any images, so that maps with an odd number of tile rows
 //     (20 and 10 pixel rows: 5 and 3) leave no wave idle (the first build tiled 8 x 128 pixels per workgroup: one
@@ -29,13 +30,18 @@
 //     B^T x = 12 operations per 6-vector) -- V never touches LDS -- and feeds it to v_mfma_f32_16x16x4_f32 as the B
 //     operand; U is the A operand, so a lane ends up with four consecutive output channels of one tile for all 36
 //     points: inverse transform and epilogue are lane-local float4 arithmetic with 16-byte accesses.
-//   * per stage and wave: 144 MFMAs (4 608 cycles) against ~580 cycles of input transform, 36 + 72 ds_read_b64 and
-//     ~20 LDS-DMA instructions; per tile the inverse transform (400 packed operations) + 32 stores (+ 32 residual
-//     loads, issued per channel group in front of that group's inverse transform).
+//   * per stage and wave (measured, 128 channels: 7 500 cycles): 144 MFMAs (4 608 cycles), the input transform
+//     (144 packed operations at 8 cycles + its 36 ds_read_b64: 1 390), 72 ds_read_b64 of U fragments (free between
+//     MFMAs), 22 LDS-DMA pieces (~24 cycles each from inside the run), one barrier; per tile the inverse transform
+//     (~230 packed operations per channel group) + 32 stores of 16 scattered 64-byte segments (~200 cycles each;
+//     those of channel group 0 are issued from inside the arithmetic of group 1 when there is no residual) + 32
+//     residual loads: 13 000 cycles.
 //   * staging is LDS-DMA (buffer_load_dwordx4 ... lds) as in emb_winograd.hip: the patch de-interleaved by column
-//     mod 4 (the 16 lanes of a tile row read consecutive 32-B rows: every ds_read_b64 covers 512 contiguous bytes),
-//     halo and out-of-image columns zero-filled by the buffer bounds check through class bits; U as one contiguous
-//     36-KB image per (32-cout slice, 8-cin stage) (weights.winograd4_pack).  22 pieces of 1 KB per wave and stage.
+//     mod 4 (the 16 lanes of a tile row read consecutive 32-B rows), halo and out-of-image columns zero-filled by the
+//     buffer bounds check through class bits; U as one contiguous 36-KB image per (32-cout slice, 8-cin stage)
+//     (weights.winograd4_pack).  22 pieces of 1 KB per wave and stage, issued as inline assembly with scalar-only
+//     set-up (wino4_piece_asm).  Both images carry a bank swizzle (emb_winograd4_geom.h) and are read with
+//     ds_read_b64 that the compiler may not fuse (w4_lds_read64): 0 LDS bank conflict cycles.
 //   * groups of 4 units are claimed at run time (tile_queue.h), in an XCD-aware order (wino4_decode).
 #include <stdlib.h>
 
