@@ -337,7 +337,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // wait above (anywhere else the compiler's own vmcnt wait for it would also wait for staging in flight), and
       // published by the barrier that opens the tile's last stage
       if (s == nstages - 1 && tid == 0) mail[0] = tq_resolve(tq, claim);
-      wino4_barrier();                                    // ... everybody's; and everybody is done with the other buffer
+      // the first column of the transform's patch reads goes out in FRONT of the barrier (the patch is this wave's own:
+      // its DMA has landed with the wait above), so that their latency overlaps the barrier instead of opening the
+      // transform; the barrier's own LDS wait comes before them
+      f32x2 x_first[6];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !defined(PA_W4_NOPATCHREAD) && !defined(PA_W4_NOTRANSFORM)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x_first[i] = w4_lds_read64(my_patch + pbase0 + wino4_patch_k(i, 0));
+#endif
+      __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done with the other buffer
+      asm volatile("" ::: "memory");
       W4_STAMP(2);
       unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
       unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
@@ -381,7 +391,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + wino4_patch_k(i, j))
 #endif
 #pragma unroll
+#ifdef PA_W4_NOPATCHREAD
         for (int i = 0; i < 6; ++i) x[0][i] = W4_RD(i, 0);
+#else
+        for (int i = 0; i < 6; ++i) x[0][i] = x_first[i];
+#endif
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           if (j + 1 < 6) {
