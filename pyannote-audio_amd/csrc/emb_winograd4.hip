@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       }
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
+      f32x2 uf_first[2][2];   // (U fragments of the first point pair, read inside the transform)
 #ifdef PA_W4_NOTRANSFORM   // development A/B (timing only): no reads, no arithmetic
 #pragma unroll
       for (int i = 0; i < 6; ++i)
@@ -419,6 +420,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         }
 #pragma unroll
         for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
+          if (i + W4_ROWS_PER_REGION >= 6) {
+            // the U fragments of the MFMA run's first point pair go out in front of the transform's last row(s):
+            // their LDS latency no longer opens the run
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+              for (int cg = 0; cg < 2; ++cg) uf_first[e][cg] = w4_lds_read64(umine + ubase + wino4_u_k(e, cg));
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int r = 0; r < W4_ROWS_PER_REGION; ++r) wino4_bt(tt[i + r], v[i + r], kc);
           __builtin_amdgcn_sched_barrier(0);
@@ -453,7 +463,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int cg = 0; cg < 2; ++cg) uf[0][e][cg] = w4_lds_read64(ub + wino4_u_k(e, cg));
+          for (int cg = 0; cg < 2; ++cg) {
+#if defined(PA_W4_NOTRANSFORM)
+            uf[0][e][cg] = w4_lds_read64(ub + wino4_u_k(e, cg));
+#else
+            uf[0][e][cg] = uf_first[e][cg];
+#endif
+          }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xp = 0; xp < 36; xp += 2) {
