@@ -563,7 +563,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // A 16-byte store of 16 scattered 64-byte segments holds its wave ~200 cycles (the write path's back-pressure,
       // not issue work).  The 16 stores of channel group 0 are therefore HELD and issued one by one from inside the
       // column arithmetic of channel group 1 (three behind each of its first four columns, two behind the last two),
-      // where those cycles are filled with vector work; group 1's own stores have nothing left to hide under.
+      // where those cycles are filled with vector work; group 1's own stores have nothing left to hide under.  (With a
+      // residual the 64 held registers spill; an epilogue in four half passes over output rows {0,1} / {2,3} -- 8 held
+      // stores at a time -- fits but reads every accumulator twice: measured 3-5 % SLOWER, profiles/r4_wino4_held_stores.txt.)
       constexpr bool DEFER = PA_W4_DEFER_STORES == 2 || (PA_W4_DEFER_STORES == 1 && !HAS_R);
       f32x4 held[4][4];
       auto store_held = [&](const int k) {   // (k: compile-time after unrolling)
