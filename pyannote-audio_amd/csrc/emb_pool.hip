@@ -15,6 +15,7 @@ namespace pa {
 
 constexpr int POOL_MAXS = 4;
 constexpr int POOL_MAXT = 512;
+constexpr int POOL_LD = 16;   // time steps whose loads are in flight together
 
 __global__ __launch_bounds__(256) void k_stats_pool(const float* __restrict__ feat, int Fh, int Tp,
                                                     int Cc, const float* __restrict__ masks, int S,
@@ -46,11 +47,19 @@ __global__ __launch_bounds__(256) void k_stats_pool(const float* __restrict__ fe
   float m[POOL_MAXS];
 #pragma unroll
   for (int s = 0; s < POOL_MAXS; ++s) m[s] = 0.f;
-  for (int t = 0; t < Tp; ++t) {
-    const float xv = x[(long)t * Cc];
+  // (loads in batches of POOL_LD: one load + a full wait per trip otherwise -- the same operations in the same order)
+  for (int t0 = 0; t0 < Tp; t0 += POOL_LD) {
+    float xb[POOL_LD];
 #pragma unroll
-    for (int s = 0; s < POOL_MAXS; ++s)
-      if (s < S) m[s] = fmaf(xv, ws[s][t], m[s]);
+    for (int u = 0; u < POOL_LD; ++u) xb[u] = t0 + u < Tp ? x[(long)(t0 + u) * Cc] : 0.f;
+#pragma unroll
+    for (int u = 0; u < POOL_LD; ++u) {
+      if (t0 + u < Tp) {
+#pragma unroll
+        for (int s = 0; s < POOL_MAXS; ++s)
+          if (s < S) m[s] = fmaf(xb[u], ws[s][t0 + u], m[s]);
+      }
+    }
   }
 #pragma unroll
   for (int s = 0; s < POOL_MAXS; ++s)
@@ -58,14 +67,21 @@ __global__ __launch_bounds__(256) void k_stats_pool(const float* __restrict__ fe
   float v[POOL_MAXS];
 #pragma unroll
   for (int s = 0; s < POOL_MAXS; ++s) v[s] = 0.f;
-  for (int t = 0; t < Tp; ++t) {
-    const float xv = x[(long)t * Cc];
+  for (int t0 = 0; t0 < Tp; t0 += POOL_LD) {
+    float xb[POOL_LD];
 #pragma unroll
-    for (int s = 0; s < POOL_MAXS; ++s)
-      if (s < S) {
-        const float d = xv - m[s];
-        v[s] = fmaf(d * d, ws[s][t], v[s]);
+    for (int u = 0; u < POOL_LD; ++u) xb[u] = t0 + u < Tp ? x[(long)(t0 + u) * Cc] : 0.f;
+#pragma unroll
+    for (int u = 0; u < POOL_LD; ++u) {
+      if (t0 + u < Tp) {
+#pragma unroll
+        for (int s = 0; s < POOL_MAXS; ++s)
+          if (s < S) {
+            const float d = xb[u] - m[s];
+            v[s] = fmaf(d * d, ws[s][t0 + u], v[s]);
+          }
       }
+    }
   }
   const int D = Cc * Fh;
   const int d = c * Fh + f;
