@@ -99,9 +99,12 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     timed = os.environ.get("PA_LINKAGE_TIMING") == "1"   # development: where the wall time of a call goes
     marks = [("start", time.perf_counter())]
 
+    host_only = os.environ.get("PA_LINKAGE_EVENTS") == "1"   # host clock at every step WITHOUT synchronising
+
     def mark(name):
         if timed:
             torch.cuda.synchronize(device)
+        if timed or host_only:
             marks.append((name, time.perf_counter()))
 
     Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device)
@@ -123,8 +126,9 @@ def linkage_centroid(X: np.ndarray, device) -> np.ndarray:
     mark("merge kernels")
     if ev:   # development: device time of the merge kernels without changing what the host does around them
         ev[1].synchronize()
-        last_linkage_phases = [("whole call", time.perf_counter() - marks[0][1]),
-                               ("merge kernels (events)", ev[0].elapsed_time(ev[1]) / 1e3)]
+        last_linkage_phases = [("host: " + b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])] + [
+            ("whole call until the events are done", time.perf_counter() - marks[0][1]),
+            ("merge kernels (events)", ev[0].elapsed_time(ev[1]) / 1e3)]
     if timed:
         last_linkage_phases = [(b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])]
     # development counters: [0:8] heap kernel (csrc/linkage.hip; all zero when the heap-free merge completed the
