@@ -114,6 +114,11 @@ int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float*
                   float* C, long ldc, int M, int N, int K, int act, int out_mode, void* stream);
 int pa_gemm_tn(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, long ldc,
                int M, int N, int K, int act, int out_mode, void* stream);
+/* the 1x1 stride-2 shortcut convolution + BatchNorm of a BasicBlock / Bottleneck (resnet.py:109-118) as the same GEMM
+ * reading pixel (2y, 2x) of the NHWC map X (B, H, W, cin) in place: C[(b, y, x)][n] = sum_c X[b][2y][2x][c] W[n][c]
+ * + bias[n]; cin % 32 == 0 */
+int pa_gemm_tn_s2(const float* X, int B, int H, int W, int cin, const float* Wt, int ldw, const float* bias, float* C,
+                  long ldc, int N, void* stream);
 int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T,
                 void* stream);
 int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, const float* cw,

@@ -162,7 +162,6 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         const int Ho = p.Hs[l + 1], Wo = p.Ws[l + 1];
         float* t1 = tmp;
         float* t2 = tmp + p.t2_off;
-        float* G = tmp + p.gather_off;
         RUN(pa_gemm_tn_ex(cur, cin, w->blk_w1[blk], cin, w->blk_shift1[blk], nullptr, t1, planes, B * H * W,
                           planes, cin, 2, 0, stream));
         if (stride == 1 && w->blk_u2[blk] != nullptr)
@@ -173,13 +172,11 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
                          1, stream));
         const float* res = cur;      // identity shortcut
         if (w->blk_wsc[blk] != nullptr) {
-          const float* src = cur;
-          if (stride == 2) {
-            RUN(pa_gather_s2(cur, B, H, W, cin, G, stream));
-            src = G;
-          }
-          RUN(pa_gemm_tn_ex(src, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], nullptr, sc, cout,
-                            B * Ho * Wo, cout, cin, 0, 0, stream));
+          if (stride == 2)
+            RUN(pa_gemm_tn_s2(cur, B, H, W, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], sc, cout, cout, stream));
+          else
+            RUN(pa_gemm_tn_ex(cur, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], nullptr, sc, cout,
+                              B * Ho * Wo, cout, cin, 0, 0, stream));
           res = sc;
         } else if (stride != 1 || cin != cout) {
           pa::set_error("pa_emb_forward: block %d needs a shortcut conv but none was given", blk);
@@ -209,11 +206,13 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         RUN(pa_conv3x3(cur, B, H, W, cin, w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1, cout, stride,
                        1, stream));
         const size_t q = (size_t)B * Ho * Wo * cin;
-        float* G = f2;
         float* R = f2 + ((q + 63) & ~(size_t)63);
-        RUN(pa_gather_s2(cur, B, H, W, cin, G, stream));
-        RUN(pa_gemm_tn(G, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, B * Ho * Wo, cout, cin,
-                       0, 0, stream));
+        // (the 1x1 stride-2 shortcut reads its pixels in place: no gathered copy)
+        if (stride == 2)
+          RUN(pa_gemm_tn_s2(cur, B, H, W, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, cout, stream));
+        else
+          RUN(pa_gemm_tn(cur, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, B * Ho * Wo, cout, cin, 0, 0,
+                         stream));
         if (w->blk_v2[blk] != nullptr && prefer_wino4(Ho, Wo, cout))
           RUN(pa_conv3x3_wino4(f1, B, Ho, Wo, cout, w->blk_v2[blk], w->blk_shift2[blk], R, cur, cout, 1,
                                stream));

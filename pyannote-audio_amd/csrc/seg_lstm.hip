@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
                                                   const float* __restrict__ Res,
                                                   float* __restrict__ C, long ldc, int M, int N, int K,
                                                   int nm, int nn, int inner, long sAo, long sAi, long sWo,
-                                                  long sWi, long sCo, long sCi) {
+                                                  long sWi, long sCo, long sCi, int gHW, int gWo, int gH, int gW) {
   if (gridDim.y > 1) {
     const int zo = blockIdx.y / inner, zi = blockIdx.y % inner;
     A += zo * sAo + zi * sAi;
@@ -64,14 +64,27 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
   const int lr = tid >> 3, lc = (tid & 7) * 4;  // loader: row lr + 32*i, 4 floats at column lc
 
   float4 ra[4], rw[4];
+  // row pointers of this thread's four A / W rows (once per tile).  gHW > 0: row m of A is pixel (2 y, 2 x) of image b
+  // of an NHWC map (b = m / gHW, y = (m % gHW) / gWo, x = m % gWo; lda = channels) -- the 1x1 stride-2 shortcut
+  // convolution of a ResNet block reads its input in place instead of through a gathered copy (k_gather_s2).
+  const float* ap[4];
+  const float* wp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ar = m0 + lr + 32 * i, wr = n0 + lr + 32 * i;
+    long arow = ar;
+    if (gHW > 0) {
+      const int b = ar / gHW, rem = ar - b * gHW, y = rem / gWo, x = rem - y * gWo;
+      arow = ((long)b * gH + 2 * y) * gW + 2 * x;
+    }
+    ap[i] = ar < M ? A + arow * lda + lc : nullptr;
+    wp[i] = wr < N ? W + (long)wr * ldw + lc : nullptr;
+  }
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int ar = m0 + lr + 32 * i, wr = n0 + lr + 32 * i;
-      ra[i] = ar < M ? *reinterpret_cast<const float4*>(A + (long)ar * lda + k0 + lc)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-      rw[i] = wr < N ? *reinterpret_cast<const float4*>(W + (long)wr * ldw + k0 + lc)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = ap[i] != nullptr ? *reinterpret_cast<const float4*>(ap[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = wp[i] != nullptr ? *reinterpret_cast<const float4*>(wp[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto lstore = [&]() {
@@ -334,8 +347,27 @@ int pa_gemm_tn_batched(const float* A, int lda, long sAo, long sAi, const float*
                        const float* bias, float* C, long ldc, long sCo, long sCi, int M, int N, int K,
                        int outer, int inner, int act, void* stream);
 
+static int gemm_tn_launch(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
+                          float* C, long ldc, int M, int N, int K, int act, int out_mode, int gHW, int gWo, int gH,
+                          int gW, void* stream);
+
 int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
                   float* C, long ldc, int M, int N, int K, int act, int out_mode, void* stream) {
+  return gemm_tn_launch(A, lda, W, ldw, bias, Res, C, ldc, M, N, K, act, out_mode, 0, 0, 0, 0, stream);
+}
+
+// C[(b, y, x)][n] = sum_c X[b][2 y][2 x][c] W[n][c] + bias[n]: the 1x1 stride-2 shortcut convolution + BatchNorm of a
+// ResNet block (models/embedding/wespeaker/resnet.py:109-118) straight from the NHWC map X (B, H, W, cin)
+int pa_gemm_tn_s2(const float* X, int B, int H, int W, int cin, const float* Wt, int ldw, const float* bias, float* C,
+                  long ldc, int N, void* stream) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (B <= 0) return 0;
+  return gemm_tn_launch(X, cin, Wt, ldw, bias, nullptr, C, ldc, B * Ho * Wo, N, cin, 0, 0, Ho * Wo, Wo, H, W, stream);
+}
+
+static int gemm_tn_launch(const float* A, int lda, const float* W, int ldw, const float* bias, const float* Res,
+                          float* C, long ldc, int M, int N, int K, int act, int out_mode, int gHW, int gWo, int gH,
+                          int gW, void* stream) {
   if (M <= 0 || N <= 0) return 0;
   PA_REQUIRE(Res == nullptr || out_mode == 0, "pa_gemm_tn_ex: a residual needs out_mode 0");
   PA_REQUIRE(K % pa::GK == 0 && lda % 4 == 0 && ldw % 4 == 0,
@@ -347,7 +379,7 @@ int pa_gemm_tn_ex(const float* A, int lda, const float* W, int ldw, const float*
   pa::ProfScope prof("k_gemm_tn", stream, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 #define PA_GEMM(ACT, OM)                                                                          \
   hipLaunchKernelGGL((pa::k_gemm_tn<ACT, OM>), dim3(grid), dim3(256), 0, st, A, lda, W, ldw, bias, \
-                     Res, C, ldc, M, N, K, nm, nn, 1, 0L, 0L, 0L, 0L, 0L, 0L)
+                     Res, C, ldc, M, N, K, nm, nn, 1, 0L, 0L, 0L, 0L, 0L, 0L, gHW, gWo, gH, gW)
   if (act == 0 && out_mode == 0) PA_GEMM(0, 0);
   else if (act == 1 && out_mode == 0) PA_GEMM(1, 0);
   else if (act == 2 && out_mode == 0) PA_GEMM(2, 0);
@@ -376,7 +408,7 @@ int pa_gemm_tn_batched(const float* A, int lda, long sAo, long sAi, const float*
   pa::ProfScope prof("k_gemm_tn", stream, 2.0 * z * M * N * K, 4.0 * z * ((double)M * K + (double)N * K + (double)M * N));
 #define PA_GEMMB(ACT)                                                                                          \
   hipLaunchKernelGGL((pa::k_gemm_tn<ACT, 0>), dim3(grid, outer * inner), dim3(256), 0, st, A, lda, W, ldw, bias, \
-                     (const float*)nullptr, C, ldc, M, N, K, nm, nn, inner, sAo, sAi, sWo, sWi, sCo, sCi)
+                     (const float*)nullptr, C, ldc, M, N, K, nm, nn, inner, sAo, sAi, sWo, sWi, sCo, sCi, 0, 0, 0, 0)
   if (act == 0) PA_GEMMB(0);
   else if (act == 3) PA_GEMMB(3);
   else PA_REQUIRE(false, "pa_gemm_tn_batched: unsupported act %d", act);
