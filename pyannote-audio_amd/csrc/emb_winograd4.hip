@@ -146,9 +146,6 @@ __device__ __forceinline__ Wino4Ctx wino4_ctx(const float* __restrict__ X, int H
   c.xnum = (int)((img - org) * 4);
   c.keep = wino4_patch_keep(u, x0_last);
   c.usoff = (n0 / W_BN) * (CIN / G::CB) * G::USLAB_BYTES;
-#ifdef PA_W4_NOPATCH   // development A/B (never in the product build): every patch lane out of bounds -> no traffic
-  c.keep = -1;
-#endif
   return c;
 }
 __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float* __restrict__ U, int COUT, int CIN,
@@ -160,9 +157,6 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
   st.usrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 36 * COUT * CIN * 4, 0x00020000);
   st.keep = c.keep;
   st.usoff = c.usoff + s * G::USLAB_BYTES;
-#ifdef PA_W4_NOU       // ... every U piece from slab 0 (L2-resident)
-  st.usoff = 0;
-#endif
   st.pbuf = pbuf;
   st.ubuf = ubuf;
   return st;
@@ -170,9 +164,6 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 
 #ifndef PA_W4_STAMP
 #define PA_W4_STAMP 0
-#endif
-#ifndef PA_W4_DMA_IN_TRANSFORM   // A/B: issue the next stage's staging between the transform's vector passes
-#define PA_W4_DMA_IN_TRANSFORM 0
 #endif
 #ifndef PA_W4_ASM_DMA   // staging pieces inside the MFMA run as inline assembly with scalar-only set-up
 #define PA_W4_ASM_DMA 1
@@ -212,11 +203,7 @@ __device__ __forceinline__ void wino4_piece(const int I, const Wino4Stage& st, c
                                             int slw) {
   using G = Wino4Geom;
   if (I < G::PINSTR) {
-#ifdef PA_W4_NOPATCH
-    const int off = pl.a[I < G::PINSTR ? I : 0] | WCLS_PAD;
-#else
     const int off = pl.a[I < G::PINSTR ? I : 0] & st.keep;
-#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.pbuf + 1024 * I), 16, off, 0, 0, 0);
   } else {
     const int k = slw + 4 * (I - G::PINSTR);
@@ -409,14 +396,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
           for (int i = 0; i < 6; ++i) tt[i][j] = y[i];
           __builtin_amdgcn_sched_barrier(0);
-#if PA_W4_DMA_IN_TRANSFORM
-          if (stage_next) {   // the 9 U pieces of the next stage, spread over the six columns
-            constexpr int first[7] = {0, 2, 3, 5, 6, 8, 9};
-#pragma unroll
-            for (int u = first[j]; u < first[j + 1]; ++u) wino4_piece(G::PINSTR + u, nst, pl, lane, slw);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#endif
         }
 #pragma unroll
         for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
@@ -432,14 +411,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
           for (int r = 0; r < W4_ROWS_PER_REGION; ++r) wino4_bt(tt[i + r], v[i + r], kc);
           __builtin_amdgcn_sched_barrier(0);
-#if PA_W4_DMA_IN_TRANSFORM
-          if (stage_next) {   // the 13 patch pieces (this wave's patch has been read completely by now)
-            constexpr int pfirst[7] = {0, 3, 5, 7, 9, 11, 13};
-#pragma unroll
-            for (int u = pfirst[i]; u < pfirst[i + 1]; ++u) wino4_piece(u, nst, pl, lane, slw);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#endif
         }
       }
 #if PA_W4_STAMP
@@ -507,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
                 for (int c2 = 0; c2 < 2; ++c2) uf[1][en][c2] = uf[0][en][c2];
             }
 #endif
-#if !defined(PA_W4_NODMA) && !PA_W4_DMA_IN_TRANSFORM   // (A/B: no staging from inside the run)
+#ifndef PA_W4_NODMA   // (development A/B, timing only: no staging from inside the run)
             if ((m == 4 || m == 6) && stage_next) {       // wave-uniform; pieces xp, xp + 1 of the next stage
               const int piece = xp + ((m - 4) >> 1);
 #if PA_W4_ASM_DMA

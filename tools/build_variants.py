@@ -11,16 +11,11 @@ VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or
     "w4defer2": ("emb_winograd4.hip", "-DPA_W4_DEFER_STORES=2", None),   # F(4x4): held stores also with a residual (spills: slower)
     "conv_prev": ("emb_resnet.hip", "", "b01ddc8"),   # k_conv3x3 with the staging offsets recomputed every stage
     "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
-    "w4s_dmatr": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_DMA_IN_TRANSFORM=1", None),   # stamps, staging issued inside the transform
-    "w4dmatr": ("emb_winograd4.hip", "-DPA_W4_DMA_IN_TRANSFORM=1", None),
-    "w4s_nopatch": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOPATCH=1", None),   # stamps, patch pieces out of bounds
     "w4s_notransform": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOTRANSFORM=1", None),
     "w4s_nopatchread": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOPATCHREAD=1", None),
     "w4s_nodma": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NODMA=1", None),     # stamps, no DMA inside the MFMA run
     "w4s_nouread": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOUREAD=1", None), # stamps, no U reads inside the run
     "w4s_neither": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NODMA=1 -DPA_W4_NOUREAD=1", None),
-    "w4nopatch": ("emb_winograd4.hip", "-DPA_W4_NOPATCH=1", None),              # F(4x4): no patch traffic (timing only)
-    "w4nomem": ("emb_winograd4.hip", "-DPA_W4_NOPATCH=1 -DPA_W4_NOU=1", None),  # ... nor U traffic
     "stamp": ("emb_winograd.hip", "-DPA_WINO_STAMP=1", None),
     "norefresh": ("emb_winograd.hip", "-DPA_WINO_REFRESH=0", None),   # 128-channel residual kernel without the pinned residual loads
     "nortouch": ("emb_winograd.hip", "-DPA_WINO_RTOUCH=0", None),   # without the residual line touch
