@@ -209,7 +209,6 @@ int pa_winograd4_pack_host(const float* conv_weight /* (cout, cin, 3, 3), resnet
                            float* U_slabs /* HOST buffer, 36 * cout * cin floats */);
 int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                      const float* R, float* Y, int cout, int relu, void* stream);
-int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream);
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream);
 

@@ -9,7 +9,6 @@
 //   k_conv3x3      implicit GEMM on v_mfma_f32_32x32x2_f32: a workgroup owns TH x (32*TWT) output
 //                  pixels x BN output channels; per 16-channel input block the (halo'd) input patch
 //                  and the 9 x BN x 16 weight slab are staged in LDS once and reused by all 9 taps.
-//   k_gather_s2    strided pixel gather feeding the 1x1/stride-2 shortcut GEMM (pa_gemm_tn).
 #include "common.h"
 
 namespace pa {
@@ -391,22 +390,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
   if (tid == 0) tq_done(tq, gridDim.x);
 }
 
-// dense rows for the 1x1 stride-2 shortcut: A[((b*Ho+y)*Wo+x)][c] = X[b][2y][2x][c]
-__global__ __launch_bounds__(256) void k_gather_s2(const float* __restrict__ X, int H, int W, int C4,
-                                                   int Ho, int Wo, long total4,
-                                                   float* __restrict__ A) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total4) return;
-  const int c4 = (int)(i % C4);
-  long p = i / C4;
-  const int x = (int)(p % Wo);
-  p /= Wo;
-  const int y = (int)(p % Ho);
-  const long b = p / Ho;
-  reinterpret_cast<float4*>(A)[i] =
-      reinterpret_cast<const float4*>(X)[(((b * H + 2 * y) * W) + 2 * x) * C4 + c4];
-}
-
 template <int S, int TH, int TWT, int BN, bool HAS_R>
 static int launch_conv_r(const float* X, int B, int H, int W, int CIN, const float* Wg,
                          const float* shift, const float* R, float* Y, int COUT, int relu,
@@ -495,18 +478,6 @@ int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, co
     PA_REQUIRE(false, "pa_conv3x3: stride %d not supported", stride);
   }
   PA_CHECK_LAUNCH("pa_conv3x3");
-  return 0;
-}
-
-int pa_gather_s2(const float* X, int B, int H, int W, int C, float* A, void* stream) {
-  PA_REQUIRE(C % 4 == 0, "pa_gather_s2: C %% 4 required");
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long total4 = (long)B * Ho * Wo * (C / 4);
-  if (total4 <= 0) return 0;
-  pa::ProfScope prof("k_gather_s2", stream, 0.0, 32.0 * total4);
-  hipLaunchKernelGGL(pa::k_gather_s2, dim3(pa::cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, X,
-                     H, W, C / 4, Ho, Wo, total4, A);
-  PA_CHECK_LAUNCH("pa_gather_s2");
   return 0;
 }
 

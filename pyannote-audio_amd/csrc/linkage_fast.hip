@@ -40,8 +40,17 @@
 // A lower-bound repair raises the bound of its row, so that workgroup's two smallest rows are no longer known: with
 // the scan minimum it publishes its two smallest rows computed WITHOUT the repaired row, which from then on travels
 // as the workgroup's third table entry -- the table always contains the two smallest bounds overall.
-// Every poll is bounded (about 2 s): a workgroup that never shows up (not resident) ends the kernel with status 3
-// and the gated heap kernel takes over -- there is no way to hang.
+// Every poll is bounded (2 s of the constant-rate wall clock, s_memrealtime; the limit in ticks is a kernel argument
+// computed from hipDeviceAttributeWallClockRate): a workgroup that never shows up (not resident) ends the kernel with
+// status 3 and the gated heap kernel takes over -- there is no way to hang.  The workgroup that gives up first
+// rewrites granule 13 of its own record with LF_ABORT, which every poll of the others looks at: they leave at their
+// next poll instead of each waiting out its own limit.
+// ORDERING.  All matrix / size / id traffic between workgroups goes through relaxed agent-scope atomics (sc1: served
+// by L2, never by a CU's vector cache), so a reader needs no acquire fence.  The WRITER side needs its stores to
+// have left the CU before the mailbox tag that announces them: every wave waits for its own outstanding stores
+// (`s_waitcnt vmcnt(0)`) in front of the workgroup barrier that precedes wave 0's mailbox store.  (An agent-scope
+// release FENCE would also write back the whole L2 -- 10 us per round, see ROUND_NOTES round 3 -- and is not needed
+// for write-through sc1 stores.)
 // hipcc-flags: -ffp-contract=off
 #include <stdlib.h>
 
@@ -64,7 +73,7 @@ constexpr int LF_W = LF_T / 64;
 constexpr int LF_PU = PA_LF_PU;
 constexpr int LF_MAXG = 16;
 constexpr lf_u64 LF_INF = 0x7ff0000000000000ULL;   // key of "no bound": +inf (NaN and negatives sort above)
-constexpr long long LF_POLL_LIMIT = 5000000000LL;  // s_memtime ticks (100 MHz domain or core clock: >= 2 s)
+constexpr lf_u32 LF_ABORT = 0xAB0127u;              // granule 13 of a record: "I gave up, leave"
 
 // distances are >= +0: the bit pattern orders like the value; -0.0 is folded into +0.0, NaN / inf into LF_INF
 __device__ __forceinline__ lf_u64 lf_key(double d) {
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
                                                         const double* __restrict__ mind0,
                                                         int* __restrict__ g_size, int* __restrict__ g_cid,
                                                         lf_u64* __restrict__ mail, int G, int SL,
+                                                        long long poll_limit /* wall-clock ticks */,
                                                         int* __restrict__ status, long long* __restrict__ stats) {
   if (MULTI && (blockIdx.x & 7) != 0) return;   // every 8th workgroup of the launch: observed to share one XCD
   const int wg = MULTI ? (int)(blockIdx.x >> 3) : 0;
@@ -355,6 +365,8 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
       }
     }
     LF_PH(0);
+    // every store of the last pass (matrix entries, sizes, ids) has left this CU before wave 0 announces them
+    if (MULTI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     LF_PH(1);
     // ================= C. wave 0: workgroup result -> exchange -> candidate table -> pop
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
         const int slot = lane >> 2, q = lane & 3;
         const bool part = slot < G;
         lf_u64 gr[4];
-        const long long t0 = __builtin_readcyclecounter();
+        const long long t0 = (long long)wall_clock64();
         for (;;) {
           bool ok = true;
 #pragma unroll
@@ -423,9 +435,17 @@ __global__ __launch_bounds__(LF_T) void k_linkage_fast(double* __restrict__ S, l
                          : ((lf_u64)seq << 32);
             ok = ok && (lf_u32)(gr[j] >> 32) == seq;
           }
-          if (__all(ok)) break;
-          if (__builtin_readcyclecounter() - t0 > LF_POLL_LIMIT) {
+          // granule 13 (q == 3, j == 1) of a record that carries this exchange's tag: 0, or LF_ABORT
+          if (__any(part && q == 3 && (lf_u32)(gr[1] >> 32) == seq && (lf_u32)gr[1] == LF_ABORT)) {
             timeout = 1;
+            break;
+          }
+          if (__all(ok)) break;
+          if ((long long)wall_clock64() - t0 > poll_limit) {
+            timeout = 1;
+            if (lane == 13)
+              __hip_atomic_store(box + wg * 16 + 13, ((lf_u64)seq << 32) | LF_ABORT, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -747,6 +767,18 @@ static int lf_num_workgroups(int n) {
   return G;
 }
 
+// bound of a mailbox poll: 2 s of the constant-rate clock wall_clock64() reads (hipDeviceAttributeWallClockRate, kHz;
+// 100 MHz on this chip); PA_LINKAGE_POLL_MS overrides (tests force a give-up with it)
+static long long lf_poll_limit_ticks() {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess ||
+      khz <= 0)
+    khz = 100000;
+  const char* e = getenv("PA_LINKAGE_POLL_MS");
+  const double ms = (e != nullptr && atof(e) > 0) ? atof(e) : 2000.0;
+  return (long long)(ms * (double)khz);
+}
+
 // launches square conversion + initial candidates + the merge kernel on `st`; *gate_out = device address of the
 // status word (0 after the kernel = Z is complete).  `stats`: 8 int64 of development counters.
 int lf_launch(const double* cond, int n, double* Z, void* workspace, long long* stats, int** gate_out,
@@ -770,19 +802,20 @@ int lf_launch(const double* cond, int n, double* Z, void* workspace, long long* 
   hipLaunchKernelGGL(k_lf_row_nearest, dim3(cdiv(n - 1, 4)), dim3(256), 0, st, cond, n, nb0, mind0);
   const int G = lf_num_workgroups(n);
   const int SL = cdiv(cdiv(n, LF_T), G);
+  const long long poll_limit = lf_poll_limit_ticks();
   if (G == 1) {
     const size_t lds = (size_t)SL * LF_T * 14;
     (void)hipFuncSetAttribute((const void*)k_linkage_fast<unsigned short, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LF_LDS_MAX);
     hipLaunchKernelGGL((k_linkage_fast<unsigned short, false>), dim3(1), dim3(LF_T), lds, st, S, ld, n, Z, nb0, mind0,
-                       g_size, g_cid, mail, 1, SL, status, stats);
+                       g_size, g_cid, mail, 1, SL, poll_limit, status, stats);
   } else {
     const size_t lds = (size_t)SL * LF_T * 16;
     if (lds > LF_LDS_MAX) return 0;   // (status stays "not run": the heap kernel does the work)
     (void)hipFuncSetAttribute((const void*)k_linkage_fast<unsigned int, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LF_LDS_MAX);
     hipLaunchKernelGGL((k_linkage_fast<unsigned int, true>), dim3(8 * G), dim3(LF_T), lds, st, S, ld, n, Z, nb0, mind0,
-                       g_size, g_cid, mail, G, SL, status, stats);
+                       g_size, g_cid, mail, G, SL, poll_limit, status, stats);
   }
   return 0;
 }

@@ -73,8 +73,9 @@ def unpack_records(rec: torch.Tensor, F: int, S: int, D: int) -> Tuple[torch.Ten
     """inverse of `pack_records` (views where possible)."""
     C = rec.shape[0]
     seg = rec[:, :F * S].reshape(C, F, S)
-    emb = rec[:, F * S:].contiguous().view(torch.float32).reshape(C, S, D)
-    return seg, emb
+    # (a copy in canonical strides: the slice of a ONE-chunk file is "contiguous" as it stands, at an unaligned offset)
+    emb_b = rec[:, F * S:].clone(memory_format=torch.contiguous_format)
+    return seg, emb_b.view(torch.float32).reshape(C, S, D)
 
 
 def _wire_device(shard: Shard, device: torch.device) -> torch.device:
@@ -108,10 +109,26 @@ def all_gather_chunks(seg_local, emb_local, total_chunks: int, shard: Shard, dev
     return unpack_records(torch.cat(parts, dim=0), F, S, D)
 
 
-MAX_FILES_PER_RANK = 61          # header capacity: 3 + 61 int64 = 512 bytes in front of the records
-_HEADER_BYTES = 8 * (3 + MAX_FILES_PER_RANK)
-_capacity: dict = {}              # (group, record bytes) -> chunks per rank every rank has agreed on
+# ---------------------------------------------------------------------------------------------------
+# many files per rank: ONE all-gather of {header, records} buffers whose size every rank derives from what it
+# has SEEN in earlier headers -- never from local information, so no rank can leave the collective alone
+# ---------------------------------------------------------------------------------------------------
+_HEADER_FIXED = 4                 # int64 words in front of the per-file counts: flag, files, chunks, record bytes
+_FILES_STEP = 64                  # the header grows in steps of 64 words (the first: 4 + 60 counts = 512 bytes)
 collectives_issued = 0            # (tests) all-gathers issued by this module
+
+
+@dataclass
+class _Agreed:
+    """what all ranks of a process group agree on before an exchange (identical on every rank: only ever updated
+    from gathered headers)"""
+    group: object                 # strong reference: keeps id(group) from being reused while the entry lives
+    record_bytes: int = 0
+    chunks: int = 0               # record capacity of a rank's buffer
+    files: int = _FILES_STEP - _HEADER_FIXED
+
+
+_agreed: dict = {}                # id(process group) -> _Agreed
 
 
 def _agreed_capacity(chunks: int) -> int:
@@ -120,55 +137,91 @@ def _agreed_capacity(chunks: int) -> int:
     return -(-int(chunks * 1.125 + 1) // 512) * 512
 
 
+def _agreed_files(files: int) -> int:
+    return -(-(files + _HEADER_FIXED) // _FILES_STEP) * _FILES_STEP - _HEADER_FIXED
+
+
+def _state_of(shard: Shard) -> _Agreed:
+    """the agreement of `shard.group` (None = the default group).  Entries of destroyed process groups are dropped:
+    a group created later starts from scratch on every rank, whatever `id()` it gets."""
+    group = shard.group if shard.group is not None else dist.group.WORLD
+    try:
+        alive = set(map(id, dist.distributed_c10d._world.pg_map))
+        for k in [k for k in _agreed if k not in alive]:
+            del _agreed[k]
+    except Exception:   # (private registry moved: entries then live as long as the process, which is harmless)
+        pass
+    st = _agreed.get(id(group))
+    if st is None or st.group is not group:
+        st = _agreed[id(group)] = _Agreed(group)
+    return st
+
+
 def all_gather_files(records: Sequence[torch.Tensor], shard: Shard, device: torch.device,
                      record_bytes: Optional[int] = None) -> List[List[torch.Tensor]]:
     """Many files.  `records`: this rank's per-file (C_f, R) uint8 record tensors.  Returns, on every rank,
     result[r][j] = records of the j-th file of rank r.
 
-    ONE all-gather per call in steady state: a rank's buffer is a fixed 512-byte header {overflow flag, number of
-    files, chunks wanted, chunks of file 0, 1, ...} followed by its records, padded to a capacity (chunks per rank)
-    that all ranks already agree on -- it is derived from the largest rank of an earlier call, so every rank
-    computes the same number without talking.  The very first call of a process group (no capacity yet), and a call
-    in which some rank's files outgrow the capacity (that rank sends its header with the overflow flag and no
-    records; every rank sees it, raises the capacity to the same new value and repeats), take TWO.
-    `record_bytes`: R, for a rank that has no file of its own (all ranks run the same models)."""
+    ONE all-gather per call in steady state: a rank's buffer is a header {flag, number of files, chunks, record
+    bytes R, chunks of file 0, 1, ...} followed by its records, padded to a capacity (files and chunks per rank,
+    R) that all ranks already agree on -- it only ever changes through numbers every rank has read from the
+    gathered headers, so every rank computes the same buffer size without talking.  The very first call of a
+    process group, and a call in which some rank's files outgrow the agreement (more chunks, more files, another
+    record size: that rank sends its header with the flag set and no records; every rank sees it, moves to the
+    same new agreement and repeats), take TWO.  Nothing is checked BEFORE the collective: a rank that cannot take
+    part as agreed says so inside it, and errors (ranks announcing different record sizes) are raised by every
+    rank together after it -- no rank is ever left waiting in an all-gather the others never enter.
+    `record_bytes`: R, for a rank that has no file of its own (all ranks run the same models); a rank that knows
+    neither simply contributes no file."""
     global collectives_issued
-    if len(records) > MAX_FILES_PER_RANK:
-        raise ValueError(f"at most {MAX_FILES_PER_RANK} files per rank and exchange")
-    R = int(records[0].shape[1]) if len(records) else int(record_bytes or 0)
-    if R <= 0:
-        raise ValueError("all_gather_files: record size unknown (no local file and no `record_bytes`)")
+    R_local = int(records[0].shape[1]) if len(records) else int(record_bytes or 0)
     counts = [int(r.shape[0]) for r in records]
     need = sum(counts)
-    key = (id(shard.group), R)
+    st = _state_of(shard)
     wire = _wire_device(shard, device)
     while True:
-        cap = _capacity.get(key, 0)
-        fits = need <= cap
-        header = torch.zeros(3 + MAX_FILES_PER_RANK, dtype=torch.int64)
-        header[0] = 0 if fits else 1
-        header[1] = len(records)
+        words = _HEADER_FIXED + st.files
+        as_agreed = (need == 0 or R_local == st.record_bytes) and need <= st.chunks and len(counts) <= st.files \
+            and (R_local in (0, st.record_bytes))
+        header = torch.zeros(words, dtype=torch.int64)
+        header[0] = 0 if as_agreed else 1
+        header[1] = len(counts)
         header[2] = need
-        header[3:3 + len(counts)] = torch.tensor(counts, dtype=torch.int64)
-        buf = torch.zeros(_HEADER_BYTES + cap * R, dtype=torch.uint8, device=device)
-        buf[:_HEADER_BYTES] = header.view(torch.uint8).to(device)
-        if fits and need:
-            buf[_HEADER_BYTES:_HEADER_BYTES + need * R] = torch.cat([r.to(device) for r in records], dim=0).reshape(-1)
+        header[3] = R_local
+        if len(counts) <= st.files:
+            header[_HEADER_FIXED:_HEADER_FIXED + len(counts)] = torch.tensor(counts, dtype=torch.int64)
+        hbytes = 8 * words
+        buf = torch.zeros(hbytes + st.chunks * st.record_bytes, dtype=torch.uint8, device=device)
+        buf[:hbytes] = header.view(torch.uint8).to(device)
+        if as_agreed and need:
+            buf[hbytes:hbytes + need * R_local] = torch.cat([r.to(device) for r in records], dim=0).reshape(-1)
         send = buf if buf.device == wire else buf.to(wire)
         recv = torch.empty((shard.world_size, send.numel()), dtype=torch.uint8, device=wire)
         dist.all_gather_into_tensor(recv.view(-1), send, group=shard.group)
         collectives_issued += 1
-        heads = recv[:, :_HEADER_BYTES].cpu().contiguous().view(torch.int64).reshape(shard.world_size, -1)
+        heads = recv[:, :hbytes].cpu().contiguous().view(torch.int64).reshape(shard.world_size, -1)
+        sizes = sorted({int(v) for v in heads[:, 3].tolist() if int(v) > 0})
+        if len(sizes) > 1:     # (every rank sees the same headers: every rank raises)
+            raise ValueError(f"all_gather_files: ranks announce different record sizes {sizes} "
+                             "(all ranks must run the same models)")
         if int(heads[:, 0].max().item()) == 0:
             break
-        _capacity[key] = _agreed_capacity(int(heads[:, 2].max().item()))   # the same on every rank
+        # the new agreement, from the headers alone
+        if sizes and sizes[0] != st.record_bytes:
+            st.record_bytes, st.chunks = sizes[0], 0
+        most_chunks, most_files = int(heads[:, 2].max().item()), int(heads[:, 1].max().item())
+        if most_chunks > st.chunks:
+            st.chunks = _agreed_capacity(most_chunks)
+        if most_files > st.files:
+            st.files = _agreed_files(most_files)
     if recv.device != device:
         recv = recv.to(device)
+    R = st.record_bytes
     out: List[List[torch.Tensor]] = []
     for r in range(shard.world_size):
-        files, pos = [], _HEADER_BYTES
+        files, pos = [], hbytes
         for j in range(int(heads[r, 1].item())):
-            c = int(heads[r, 3 + j].item())
+            c = int(heads[r, _HEADER_FIXED + j].item())
             files.append(recv[r, pos:pos + c * R].reshape(c, R))
             pos += c * R
         out.append(files)

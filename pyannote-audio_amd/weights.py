@@ -208,8 +208,8 @@ def wav2vec_config(wav2vec) -> dict:
         if os.path.isfile(wav2vec):
             # a self-supervised checkpoint {"config": wav2vec2_model kwargs, "state_dict": ...}
             # (SSeRiouSS.py:111-119); its weights are superseded by the model checkpoint's own `wav2vec.*` entries,
-            # only the architecture is read here
-            checkpoint = torch.load(wav2vec, map_location="cpu", weights_only=False)
+            # only the architecture is read here, so the safe loader suffices (plain containers + tensors)
+            checkpoint = torch.load(wav2vec, map_location="cpu", weights_only=True)
             if "config" not in checkpoint:
                 raise ValueError(f"wav2vec checkpoint {wav2vec!r} has no 'config' entry (SSeRiouSS.py:113)")
             wav2vec = checkpoint["config"]

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, q):
+def _worker(rank, world, port, total, q, port2=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -78,9 +78,43 @@ def _worker(rank, world, port, total, q):
     before = parallel.collectives_issued
     ok = ok and check(parallel.all_gather_files(recs2, shard, torch.device("cpu")), lens2, files2)
     assert parallel.collectives_issued - before == 1
+    # more files on one rank than the header holds (60): the header capacity is part of the agreement and grows
+    # through the same flag round -- nobody raises before the collective, nobody is left waiting in it
+    many = [(rng.uniform(size=(1 + (i % 3), 37, 3)) < 0.4, rng.standard_normal((1 + (i % 3), 3, 16)).astype(np.float32))
+            for i in range(70)]
+    lens3, files3 = [[5, 2], [m[0].shape[0] for m in many]], files[:2] + many
+    mine3 = files3[:2] if rank == 0 else many
+    recs3 = [parallel.pack_records(torch.from_numpy(sg), torch.from_numpy(em)) for sg, em in mine3]
+    before = parallel.collectives_issued
+    ok = ok and check(parallel.all_gather_files(recs3, shard, torch.device("cpu")), lens3, files3)
+    assert parallel.collectives_issued - before == 2
+    before = parallel.collectives_issued
+    ok = ok and check(parallel.all_gather_files(recs3, shard, torch.device("cpu")), lens3, files3)
+    assert parallel.collectives_issued - before == 1
+    # a rank that has neither a file nor the record size contributes nothing (and stalls nobody)
+    got = parallel.all_gather_files(recs if rank == 0 else [], shard, torch.device("cpu"))
+    ok = ok and len(got[1]) == 0 and len(got[0]) == 2
+    # ranks that announce different record sizes: EVERY rank raises, after the collective
+    odd = [torch.zeros((2, 99 if rank == 0 else 98), dtype=torch.uint8)]
+    try:
+        parallel.all_gather_files(odd, shard, torch.device("cpu"))
+        ok = False
+    except ValueError as err:
+        ok = ok and "different record sizes" in str(err)
     q.put((rank, b, e, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
+    if port2 is not None:
+        # a NEW process group of the same process starts without an agreement, whatever id() it gets
+        os.environ["MASTER_PORT"] = str(port2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        shard = parallel.shard_from_env()
+        before = parallel.collectives_issued
+        good = check(parallel.all_gather_files(recs, shard, torch.device("cpu")), lens, files)
+        assert parallel.collectives_issued - before == 2 and good
+        assert len(parallel._agreed) == 1
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("total", [21, 8, 3])
@@ -89,7 +123,8 @@ def test_all_gather_chunks_gloo(total):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    port2 = _free_port() if total == 21 else None
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q, port2)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))

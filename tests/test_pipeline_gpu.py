@@ -195,6 +195,60 @@ def test_linkage_late_tie_falls_back_to_the_heap(gpu_device, wgs, monkeypatch):
     assert st[8] == 1 and st[15] == 72 and st[7] == len(X)   # gave up at merge 72, like the model; the heap ran
 
 
+def test_linkage_heap_free_merge_under_memory_load(gpu_device):
+    """the multi-workgroup merge publishes matrix updates to its peers through relaxed sc1 stores + a mailbox tag
+    (csrc/linkage_fast.hip, ORDERING): run it while a second stream saturates HBM with copies -- store
+    acknowledgements then take far longer than in an idle chip -- and require SciPy's dendrogram bit for bit,
+    completed by the heap-free kernel itself (status 0), three times in a row."""
+    import torch
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+    from pyannote_audio_amd import distance
+    n, d = 12300, 32
+    rng = np.random.default_rng(77)
+    centers = rng.standard_normal((4, d))
+    X = (centers[rng.integers(0, 4, n)] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    want = linkage(pdist(X), method="centroid")
+    side = torch.cuda.Stream(device=gpu_device)
+    a = torch.empty(1 << 28, dtype=torch.float32, device=gpu_device)   # 1 GB each: far beyond L2 + Infinity Cache
+    b = torch.empty_like(a)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(400):          # ~ 0.3 s of back-to-back 2-GB copies at HBM rate
+                b.copy_(a, non_blocking=True)
+        got = distance.linkage_centroid(X, gpu_device)
+        st = distance.last_linkage_stats
+        side.synchronize()
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, f"rep {rep}: first differing merge {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
+        assert st[8] == 0 and st[13] == 16, f"rep {rep}: status {st[8]}, workgroups {st[13]}"
+
+
+def test_linkage_poll_limit_gives_up_together(gpu_device, monkeypatch):
+    """a mailbox poll that runs into its limit (forced: PA_LINKAGE_POLL_MS = 10 ns) ends the heap-free kernel with
+    status 3 in EVERY workgroup (the one that gives up first tells the others through its record) and the gated heap
+    kernel delivers SciPy's dendrogram; the call returns promptly instead of after one limit per workgroup."""
+    import time
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+    from pyannote_audio_amd import distance
+    monkeypatch.setenv("PA_LINKAGE_POLL_MS", "0.00001")
+    n, d = 12300, 32
+    rng = np.random.default_rng(78)
+    centers = rng.standard_normal((4, d))
+    X = (centers[rng.integers(0, 4, n)] + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    want = linkage(pdist(X), method="centroid")
+    t0 = time.perf_counter()
+    got = distance.linkage_centroid(X, gpu_device)
+    dt = time.perf_counter() - t0
+    st = distance.last_linkage_stats
+    assert np.array_equal(got, want)
+    assert st[8] == 3 and st[7] == n, f"status {st[8]} (expected 3: gave up), heap kernel n {st[7]}"
+    assert dt < 20.0
+
+
 @pytest.mark.parametrize("n,d,k,seed", [(1, 256, 1, 0), (40, 256, 1, 1), (500, 256, 7, 2), (7176, 256, 50, 3),
                                         (3000, 300, 13, 4), (9, 16, 20, 5)])
 def test_centroid_means_bit_exact(gpu_device, n, d, k, seed):
