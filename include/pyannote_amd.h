@@ -260,7 +260,7 @@ typedef struct pa_sser_weights {
   const float* proj_b;
   const float* pos_w;     /* [groups][kernel][D/groups (in)][D/groups (out)], weight_norm materialised */
   const float* pos_b;     /* [D] */
-  const float* enc_ln_g;  /* encoder.transformer.layer_norm (applied up front when layer_norm_first) */
+  const float* enc_ln_g;  /* encoder.transformer.layer_norm: in front of the layers iff !layer_norm_first (post-LN) */
   const float* enc_ln_b;
   pa_w2v_layer layers[PA_W2V_MAX_LAYERS];
   float layer_mix[PA_W2V_MAX_LAYERS];      /* softmax(wav2vec_weights) */

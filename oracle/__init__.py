@@ -25,7 +25,10 @@ stand-ins themselves:
   * `asteroid_filterbanks.ParamSincFB` (0.4.0) and `torchaudio.compliance.kaldi.fbank`
     (2.10.0) live in third-party packages that are neither vendored in /root/reference nor
     installed here: they are restated from their published algorithm  ==> PARITY UNPINNED
-    for those two functions (and therefore for end-to-end numbers that depend on them).
+    for those two functions (and therefore for end-to-end numbers that depend on them); independent
+    implementations bound them: tests/test_oracle_sincnet_pin.py, tests/test_oracle_fbank_pin.py.
+  * torchaudio's wav2vec 2.0 / WavLM encoder (oracle/wav2vec2.py) is pinned layer by layer to HuggingFace
+    transformers (tests/test_oracle_wav2vec2_pin.py).
   * `pyannote.core` (Segment / SlidingWindow / closest_frame) is restated from its published
     semantics; nothing in the reference's tests pins it numerically.
 

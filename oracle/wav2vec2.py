@@ -1,12 +1,18 @@
 """Oracle (CPU) restatement of torchaudio's wav2vec 2.0 / WavLM encoder -- TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: torchaudio 2.10.0 (`torchaudio.models.wav2vec2_model`, `wavlm_model`,
-`torchaudio.pipelines.WAVLM_BASE`) is a third-party dependency of the reference
-(models/segmentation/SSeRiouSS.py:29, 100-124) that is neither vendored under /root/reference nor installed
-here, and there is no network.  What follows restates its PUBLISHED architecture (Baevski et al. 2020,
-"wav2vec 2.0"; Chen et al. 2022, "WavLM", section 3.1 + the gated relative position bias of eq. 3-5) with
-torchaudio's module / parameter names (components.py, wavlm_attention.py), so that a real checkpoint's
-state dict would load; a deviation of torchaudio's code from this restatement would go unnoticed.
+torchaudio 2.10.0 (`torchaudio.models.wav2vec2_model`, `wavlm_model`, `torchaudio.pipelines.WAVLM_BASE`) is a
+third-party dependency of the reference (models/segmentation/SSeRiouSS.py:29, 100-124) that is neither vendored
+under /root/reference nor installed here, and there is no network.  What follows restates its PUBLISHED
+architecture (Baevski et al. 2020, "wav2vec 2.0"; Chen et al. 2022, "WavLM", section 3.1 + the gated relative
+position bias of eq. 3-5) with torchaudio's module / parameter names (components.py, wavlm_attention.py), so that
+a real checkpoint's state dict loads.
+
+PINNED (round 5) by an independent implementation that IS installed: HuggingFace `transformers`
+(`Wav2Vec2Model`, `WavLMModel`; post-LN and pre-LN, group- and layer-norm extractors), random weights renamed
+key by key through the mapping of torchaudio's `import_huggingface_model` and loaded here with strict=True --
+tests/test_oracle_wav2vec2_pin.py: every layer's output agrees to 2e-5.  (That test found the one deviation of
+the round-3 restatement: the encoder-level LayerNorm of a post-LN model belongs in FRONT of the layers.)
+What it cannot see is a deviation of torchaudio's code from the architecture both implement.
 The reference's OWN file (SSeRiouSS.py: layer weighting, LSTM, head) is executed for real on top of this
 module by tests/test_reference_pipeline.py.
 
@@ -271,7 +277,10 @@ def _model(wavlm: bool, extractor_mode, extractor_conv_layer_config, extractor_c
                                    FeedForward(encoder_embed_dim, encoder_ff_interm_features)))
     transformer = Transformer(ConvolutionalPositionalEmbedding(encoder_embed_dim, encoder_pos_conv_kernel,
                                                                encoder_pos_conv_groups),
-                              layers, encoder_embed_dim, encoder_layer_norm_first)
+                              # torchaudio's `_get_encoder` hands the Transformer `not layer_norm_first`: the
+                              # encoder-level LayerNorm sits in FRONT of the layers of a post-LN (base) model and
+                              # behind the last layer of a pre-LN one (fairseq / HF agree: tests/test_oracle_wav2vec2_pin.py)
+                              layers, encoder_embed_dim, not encoder_layer_norm_first)
     return Wav2Vec2Model(fe, Encoder(FeatureProjection(shapes[-1][0], encoder_embed_dim), transformer))
 
 

@@ -187,7 +187,11 @@ int pa_sser_forward(const pa_sser_weights* w, const float* wav, int64_t wav_len,
   RUN(pa_w2v_layernorm(feat, cb[w->num_conv & 1], M, C, w->proj_ln_g, w->proj_ln_b, 0, stream));
   RUN(pa_gemm_tn_ex(cb[w->num_conv & 1], C, w->proj_w, C, w->proj_b, nullptr, x2, D, M, D, C, 0, 0, stream));
   RUN(pa_w2v_posconv(x2, B, T, P, D, w->pos_groups, w->pos_kernel, w->pos_w, w->pos_b, x, stream));
-  if (w->layer_norm_first) RUN(pa_w2v_layernorm(x, x, M, D, w->enc_ln_g, w->enc_ln_b, 0, stream));
+  // the encoder-level LayerNorm precedes the layers of a POST-LN model (torchaudio's `_get_encoder` builds the
+  // Transformer with `not layer_norm_first`; fairseq / HuggingFace agree -- tests/test_oracle_wav2vec2_pin.py).  In a
+  // pre-LN model it follows the last layer in `forward`, which `extract_features` (the call of SSeRiouSS.py:289-296)
+  // never reaches.
+  if (!w->layer_norm_first) RUN(pa_w2v_layernorm(x, x, M, D, w->enc_ln_g, w->enc_ln_b, 0, stream));
   if (hipMemsetAsync(ws + p.vt, 0, sizeof(float) * (size_t)B * D * Tp, st) != hipSuccess) return 1;
   if (hipMemsetAsync(ws + p.o, 0, sizeof(float) * (size_t)M * D, st) != hipSuccess) return 1;
 

@@ -3,7 +3,8 @@
 attention with WavLM's gated relative position bias, GELU MLPs), the layer mix, then the PyanNet LSTM / head
 kernels -- against oracle.models.SSeRiouSS.  The reference's own SSeRiouSS.py is pinned bit for bit to that
 oracle class by tests/test_reference_pipeline.py; the encoder underneath (torchaudio, absent offline) is the
-restatement in oracle/wav2vec2.py: PARITY UNPINNED for it.  Tolerance: rtol 1e-4 / atol 1e-5 on log-probs."""
+restatement in oracle/wav2vec2.py, pinned layer by layer to HuggingFace transformers' Wav2Vec2Model / WavLMModel
+by tests/test_oracle_wav2vec2_pin.py.  Tolerance: rtol 1e-4 / atol 1e-5 on log-probs."""
 import os
 
 import numpy as np
