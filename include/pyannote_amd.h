@@ -184,6 +184,21 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
                    const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
                    void* stream);
 
+/* Numerical guard of the Winograd paths (weights.EmbeddingPack runs it once per loaded checkpoint; the reference has
+ * no counterpart: its convolutions are torch's direct fp32 ones, resnet.py:92-107).  The chunks go through a
+ * BasicBlock network in which every stride-1 3x3 convolution is evaluated by the DIRECT kernel (whose output feeds
+ * the next layer) and, beside it, by every Winograd image the block carries.
+ * report (device, 8 * PA_MAX_RES_BLOCKS floats, zeroed by the call): for block b, convolution j in {0, 1}:
+ *   report[4 (2 b + j) + 0] = max |direct|,  [+1] = max |F(4x4) - direct|   (both 0: no F(4x4) image)
+ *   report[4 (2 b + j) + 2] = max |direct|,  [+3] = max |F(2x2) - direct|   (both 0: no F(2x2) image)
+ * over the whole output map (after shift, residual and ReLU).  emb: (num_chunks, embed_dim) from the direct path. */
+size_t pa_emb_calibrate_workspace_bytes(const pa_emb_weights* w, int num_chunks, int num_samples);
+int pa_emb_calibrate_winograd(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                              int num_chunks, int num_samples, float* report, float* emb, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* out2[0] = max(out2[0], max |ref|), out2[1] = max(out2[1], max |got - ref|) over n floats (out2 >= 0 on entry) */
+int pa_absmax_diff(const float* got, const float* ref, long n, float* out2, void* stream);
+
 int pa_fbank(const float* wav, long wav_len, long chunk_stride, int B, int N, const float* window,
              const float* tw256, const float* tw512, const float* mel_w, const int* mel_lo,
              const int* mel_hi, int nmel, float* out, int center, void* stream);

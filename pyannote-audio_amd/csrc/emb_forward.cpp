@@ -38,7 +38,7 @@ inline bool prefer_wino4(int H, int W, int cin) {
   return p4 * 100 <= p2 * gain;
 }
 
-bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p) {
+bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p, bool calib = false) {
   if (N < 400) return false;
   p->B = B;
   p->N = N;
@@ -82,6 +82,8 @@ bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p) {
     p->t2_off = align64(t1);
     p->gather_off = p->t2_off + align64(t2);
     p->act[3] = take(p->gather_off + align64(g));
+  } else if (calib) {
+    p->act[3] = take(p->act_elems);   // where the Winograd result of a convolution waits for its comparison
   }
   const int L = w->num_layers;
   p->stats = take((size_t)B * p->S * 2 * w->planes[L - 1] * ex * p->Hs[L]);
@@ -109,13 +111,20 @@ size_t pa_emb_workspace_bytes(const pa_emb_weights* w, int num_chunks, int num_s
   return p.total * sizeof(float);
 }
 
-int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
-                   int num_chunks, int num_samples, const float* masks, int num_masks, int mask_frames,
-                   const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
-                   void* stream) {
+}  // extern "C"
+
+extern "C" int pa_absmax_diff(const float* got, const float* ref, long n, float* out2, void* stream);   // emb_pool.hip
+
+// `calib` (pa_emb_calibrate_winograd): every stride-1 3x3 convolution of a BasicBlock network runs through the
+// DIRECT kernel -- whose result the following layers see -- and, beside it, through each Winograd image its block
+// carries; calib[4 (2 blk + j) ...] = {max |direct|, max |F(4x4) - direct|, max |direct|, max |F(2x2) - direct|}.
+static int emb_forward_impl(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                            int num_chunks, int num_samples, const float* masks, int num_masks, int mask_frames,
+                            const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
+                            void* stream, float* calib) {
   if (num_chunks <= 0) return 0;
   EmbPlan p;
-  if (w->num_layers != 4 || !make_plan(w, num_chunks, num_samples, masks ? num_masks : 1, &p)) {
+  if (w->num_layers != 4 || !make_plan(w, num_chunks, num_samples, masks ? num_masks : 1, &p, calib != nullptr)) {
     pa::set_error("pa_emb_forward: %d samples is too short (fbank needs >= 400) or bad layer count",
                   num_samples);
     return 3;
@@ -140,6 +149,30 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
   float* f1 = ws + p.act[1];
   float* f2 = ws + p.act[2];
   RUN(pa_resnet_stem(ws + p.fbank, B, p.T, p.F, w->stem_w, w->stem_shift, cur, stream));
+
+  // a stride-1 3x3 convolution (+ shift, residual R, ReLU) of a BasicBlock: F(4x4) where it pays, else F(2x2), else
+  // the direct kernel -- as far as the block carries the images (the numerical guard of EmbeddingPack removes them)
+  auto conv_s1 = [&](const float* X, int H, int W, int ci, const float* v, const float* u, const float* wd,
+                     const float* shift, const float* R, float* Y, int co, int slot) -> int {
+    if (calib != nullptr) {
+      float* scratch = ws + p.act[3];
+      float* rep = calib + 4 * slot;
+      const long n = (long)B * H * W * co;
+      int r = pa_conv3x3(X, B, H, W, ci, wd, shift, R, Y, co, 1, 1, stream);
+      if (r == 0 && v != nullptr) {
+        r = pa_conv3x3_wino4(X, B, H, W, ci, v, shift, R, scratch, co, 1, stream);
+        if (r == 0) r = pa_absmax_diff(scratch, Y, n, rep, stream);
+      }
+      if (r == 0 && u != nullptr) {
+        r = pa_conv3x3_wino(X, B, H, W, ci, u, shift, R, scratch, co, 1, stream);
+        if (r == 0) r = pa_absmax_diff(scratch, Y, n, rep + 2, stream);
+      }
+      return r;
+    }
+    if (v != nullptr && prefer_wino4(H, W, ci)) return pa_conv3x3_wino4(X, B, H, W, ci, v, shift, R, Y, co, 1, stream);
+    if (u != nullptr) return pa_conv3x3_wino(X, B, H, W, ci, u, shift, R, Y, co, 1, stream);
+    return pa_conv3x3(X, B, H, W, ci, wd, shift, R, Y, co, 1, 1, stream);
+  };
 
   int blk = 0;
   int cin = w->planes[0];
@@ -213,38 +246,17 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
         else
           RUN(pa_gemm_tn(cur, cin, w->blk_wsc[blk], cin, w->blk_shiftsc[blk], R, cout, B * Ho * Wo, cout, cin, 0, 0,
                          stream));
-        if (w->blk_v2[blk] != nullptr && prefer_wino4(Ho, Wo, cout))
-          RUN(pa_conv3x3_wino4(f1, B, Ho, Wo, cout, w->blk_v2[blk], w->blk_shift2[blk], R, cur, cout, 1,
-                               stream));
-        else if (w->blk_u2[blk] != nullptr)
-          RUN(pa_conv3x3_wino(f1, B, Ho, Wo, cout, w->blk_u2[blk], w->blk_shift2[blk], R, cur, cout, 1,
-                              stream));
-        else
-          RUN(pa_conv3x3(f1, B, Ho, Wo, cout, w->blk_w2[blk], w->blk_shift2[blk], R, cur, cout, 1, 1,
-                         stream));
+        RUN(conv_s1(f1, Ho, Wo, cout, w->blk_v2[blk], w->blk_u2[blk], w->blk_w2[blk], w->blk_shift2[blk], R, cur, cout,
+                    2 * blk + 1));
       } else {
         if (stride != 1 || cin != cout) {
           pa::set_error("pa_emb_forward: block %d needs a shortcut conv but none was given", blk);
           return 3;
         }
-        if (w->blk_v1[blk] != nullptr && prefer_wino4(H, W, cin))
-          RUN(pa_conv3x3_wino4(cur, B, H, W, cin, w->blk_v1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1,
-                               stream));
-        else if (w->blk_u1[blk] != nullptr)
-          RUN(pa_conv3x3_wino(cur, B, H, W, cin, w->blk_u1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1,
-                              stream));
-        else
-          RUN(pa_conv3x3(cur, B, H, W, cin, w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1, cout, 1, 1,
-                         stream));
-        if (w->blk_v2[blk] != nullptr && prefer_wino4(H, W, cout))
-          RUN(pa_conv3x3_wino4(f1, B, H, W, cout, w->blk_v2[blk], w->blk_shift2[blk], cur, f2, cout, 1,
-                               stream));
-        else if (w->blk_u2[blk] != nullptr)
-          RUN(pa_conv3x3_wino(f1, B, H, W, cout, w->blk_u2[blk], w->blk_shift2[blk], cur, f2, cout, 1,
-                              stream));
-        else
-          RUN(pa_conv3x3(f1, B, H, W, cout, w->blk_w2[blk], w->blk_shift2[blk], cur, f2, cout, 1, 1,
-                         stream));
+        RUN(conv_s1(cur, H, W, cin, w->blk_v1[blk], w->blk_u1[blk], w->blk_w1[blk], w->blk_shift1[blk], nullptr, f1,
+                    cout, 2 * blk));
+        RUN(conv_s1(f1, H, W, cout, w->blk_v2[blk], w->blk_u2[blk], w->blk_w2[blk], w->blk_shift2[blk], cur, f2, cout,
+                    2 * blk + 1));
         float* t = cur;
         cur = f2;
         f2 = t;
@@ -261,6 +273,34 @@ int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, i
                  0, 0, stream));
 #undef RUN
   return 0;
+}
+
+extern "C" {
+
+int pa_emb_forward(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                   int num_chunks, int num_samples, const float* masks, int num_masks, int mask_frames,
+                   const int32_t* nearest_idx, float* emb, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+  return emb_forward_impl(w, wav, wav_len, chunk_stride, num_chunks, num_samples, masks, num_masks, mask_frames,
+                          nearest_idx, emb, workspace, workspace_bytes, stream, nullptr);
+}
+
+size_t pa_emb_calibrate_workspace_bytes(const pa_emb_weights* w, int num_chunks, int num_samples) {
+  EmbPlan p;
+  if (!make_plan(w, num_chunks, num_samples, 1, &p, true)) return 0;
+  return p.total * sizeof(float);
+}
+
+int pa_emb_calibrate_winograd(const pa_emb_weights* w, const float* wav, int64_t wav_len, int64_t chunk_stride,
+                              int num_chunks, int num_samples, float* report, float* emb, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (w->bottleneck) {
+    pa::set_error("pa_emb_calibrate_winograd: BasicBlock networks only (Bottleneck blocks run F(2x2) / direct)");
+    return 3;
+  }
+  if (hipMemsetAsync(report, 0, sizeof(float) * 8 * PA_MAX_RES_BLOCKS, (hipStream_t)stream) != hipSuccess) return 1;
+  return emb_forward_impl(w, wav, wav_len, chunk_stride, num_chunks, num_samples, nullptr, 1, 0, nullptr, emb,
+                          workspace, workspace_bytes, stream, report);
 }
 
 }  // extern "C"

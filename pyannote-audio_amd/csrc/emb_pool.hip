@@ -174,6 +174,28 @@ __global__ __launch_bounds__(256) void k_stats_pool_rows(const float* __restrict
     }
 }
 
+// calibration of the Winograd paths (pa_emb_calibrate_winograd): out[0] = max(out[0], max |ref|),
+// out[1] = max(out[1], max |got - ref|) over n floats.  Non-negative floats order like their bit patterns, so the
+// cross-workgroup maximum is an integer atomicMax; NaN in `got` counts as +inf.
+__global__ __launch_bounds__(256) void k_absmax_diff(const float* __restrict__ got, const float* __restrict__ ref,
+                                                     long n, float* __restrict__ out) {
+  float mr = 0.f, md = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float r = ref[i], d = fabsf(got[i] - r);
+    mr = fmaxf(mr, fabsf(r));
+    md = d == d ? fmaxf(md, d) : __builtin_inff();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mr = fmaxf(mr, __shfl_xor(mr, o, 64));
+    md = fmaxf(md, __shfl_xor(md, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(mr));
+    atomicMax(reinterpret_cast<unsigned int*>(out) + 1, __float_as_uint(md));
+  }
+}
+
 }  // namespace pa
 
 extern "C" {
@@ -202,6 +224,14 @@ int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* 
   hipLaunchKernelGGL(pa::k_stats_pool, dim3(pa::cdiv(C, 256), Fh, B), dim3(256), 0,
                      (hipStream_t)stream, feat, Fh, Tp, C, masks, S, Fm, nearest_idx, stats);
   PA_CHECK_LAUNCH("pa_stats_pool");
+  return 0;
+}
+
+int pa_absmax_diff(const float* got, const float* ref, long n, float* out2, void* stream) {
+  if (n <= 0) return 0;
+  const int grid = pa::cdiv(n, 256 * 8) > 2048 ? 2048 : pa::cdiv(n, 256 * 8);
+  hipLaunchKernelGGL(pa::k_absmax_diff, dim3(grid), dim3(256), 0, (hipStream_t)stream, got, ref, n, out2);
+  PA_CHECK_LAUNCH("pa_absmax_diff");
   return 0;
 }
 

@@ -530,7 +530,8 @@ class EmbeddingPack:
     shortcut.1}, resnet.seg_1."""
 
     def __init__(self, state_dict: dict, device: torch.device, num_blocks=None,
-                 num_mel: int = 80, sample_rate: int = 16000, winograd: Optional[bool] = None):
+                 num_mel: int = 80, sample_rate: int = 16000, winograd: Optional[bool] = None,
+                 guard: Optional[bool] = None):
         if winograd is None:
             winograd = os.environ.get("PA_WINOGRAD", "1") != "0"
         self.winograd = winograd
@@ -619,6 +620,85 @@ class EmbeddingPack:
         w.seg1_w = self._up(sd["resnet.seg_1.weight"])
         w.seg1_b = self._up(sd["resnet.seg_1.bias"])
         self.struct = w
+        self.winograd_guard: list[dict] = []
+        if guard is None:
+            guard = os.environ.get("PA_WINOGRAD_GUARD", "1") != "0"
+        if guard and winograd and not self.bottleneck and device.type == "cuda":
+            self._guard_winograd()
+
+    #: the guard's margins on  max |Winograd - direct| / max |direct|  over a convolution's output map (after shift,
+    #: residual and ReLU) for the calibration chunks.  On the seeded / BatchNorm-randomised ResNet34 of the test suite
+    #: the statistic is 0.3 - 2.5e-6 for F(4x4) and 0.6 - 8e-7 for F(2x2) (the direct fp32 kernel itself is 0.5 - 5e-7
+    #: away from a float64 evaluation); the margins leave a factor ~6 / ~12 above that.  A demotion costs speed only.
+    WINOGRAD_GUARD_MARGINS = {"f4": 1.5e-5, "f2": 1.0e-5}
+
+    @staticmethod
+    def calibration_chunks(num_samples: int = 48000) -> torch.Tensor:
+        """the guard's fixed input: two seeded, speech-like 3-s chunks (glottal-pulse-like harmonic series at 120 /
+        210 Hz under a 4-Hz syllable envelope + noise floor), (2, num_samples) float32 at 16 kHz, RMS ~ 0.1"""
+        g = torch.Generator().manual_seed(20250923)
+        t = torch.arange(num_samples, dtype=torch.float64) / 16000.0
+        out = []
+        for f0 in (120.0, 210.0):
+            k = torch.arange(1, int(7000 // f0), dtype=torch.float64)
+            phase = 2 * math.pi * torch.rand(len(k), generator=g, dtype=torch.float64)
+            tilt = 1.0 / k * (1.0 + 0.8 * torch.cos(2 * math.pi * k * f0 / 2300.0))      # a coarse formant ripple
+            glide = f0 * (1.0 + 0.08 * torch.sin(2 * math.pi * 0.7 * t))
+            inst = 2 * math.pi * torch.cumsum(glide, 0) / 16000.0
+            x = (tilt[:, None] * torch.sin(k[:, None] * inst[None, :] + phase[:, None])).sum(0)
+            env = 0.55 + 0.45 * torch.sin(2 * math.pi * 4.0 * t + phase[0])
+            x = x * env + 0.05 * torch.randn(num_samples, generator=g, dtype=torch.float64)
+            out.append(0.1 * x / x.pow(2).mean().sqrt())
+        return torch.stack(out).float()
+
+    def _guard_winograd(self):
+        """Numerical guard of the Winograd paths: with the LOADED weights, every stride-1
+        3x3 convolution is evaluated on the activations the calibration chunks produce in this very network -- by the
+        direct kernel and by each Winograd image -- and an image whose result strays from the direct one by more
+        than its margin is dropped: F(4x4) -> F(2x2) -> direct, per convolution.  F(4x4,3x3) multiplies by 8 and 1/24
+        in its transforms: harmless for weights and activations of ordinary spread (BatchNorm keeps them there),
+        but a checkpoint whose convolution cancels a large common component of its input (output << sum |w||x|)
+        loses those digits first.  Decisions are kept in `self.winograd_guard` and logged."""
+        import logging
+        lib = ffi.load()
+        w = self.struct
+        log = logging.getLogger("pyannote_audio_amd")
+        m4 = float(os.environ.get("PA_WINOGRAD_GUARD_F4", self.WINOGRAD_GUARD_MARGINS["f4"]))
+        m2 = float(os.environ.get("PA_WINOGRAD_GUARD_F2", self.WINOGRAD_GUARD_MARGINS["f2"]))
+        with torch.cuda.device(self.device):
+            wav = self.calibration_chunks().to(self.device)
+            B, N = wav.shape
+            report = torch.zeros(8 * ffi.PA_MAX_RES_BLOCKS, dtype=torch.float32, device=self.device)
+            emb = torch.empty((B, int(w.embed_dim)), dtype=torch.float32, device=self.device)
+            ws = torch.empty(lib.pa_emb_calibrate_workspace_bytes(w, B, N), dtype=torch.uint8, device=self.device)
+            ffi.check(lib.pa_emb_calibrate_winograd(w, ffi.ptr(wav.view(-1)), B * N, N, B, N, ffi.ptr(report),
+                                                    ffi.ptr(emb), ffi.ptr(ws), ws.numel(), ffi.stream()),
+                      "pa_emb_calibrate_winograd")
+            rep = report.cpu().view(-1, 2, 4).numpy()
+        blk = 0
+        for l in range(4):
+            for i in range(self.num_blocks[l]):
+                for j in (0, 1):
+                    ref4, d4, ref2, d2 = (float(v) for v in rep[blk, j])
+                    if ref4 == 0.0 and ref2 == 0.0:
+                        continue          # a strided convolution, or no Winograd image: nothing to guard
+                    entry = {"layer": l + 1, "block": i, "conv": j + 1,
+                             "f4": d4 / ref4 if ref4 > 0 else None, "f2": d2 / ref2 if ref2 > 0 else None}
+                    ok4 = ref4 > 0 and entry["f4"] <= m4          # (NaN compares false)
+                    ok2 = ref2 > 0 and entry["f2"] <= m2
+                    if ref4 > 0 and not ok4:
+                        getattr(w, f"blk_v{j + 1}")[blk] = None
+                    if ref2 > 0 and not ok2:    # (also F(4x4)'s stand-in on maps where F(4x4) does not pay)
+                        getattr(w, f"blk_u{j + 1}")[blk] = None
+                    path = "f4" if ok4 else ("f2" if ok2 else "direct")
+                    entry["path"] = path
+                    self.winograd_guard.append(entry)
+                    if path != ("f4" if ref4 > 0 else "f2"):
+                        log.warning("layer%d.%d.conv%d: Winograd F(4x4) error %s, F(2x2) error %s of the output "
+                                    "maximum (margins %.1e / %.1e) -> %s kernel", l + 1, i, j + 1,
+                                    "%.2e" % entry["f4"] if entry["f4"] is not None else "n/a",
+                                    "%.2e" % entry["f2"] if entry["f2"] is not None else "n/a", m4, m2, path)
+                blk += 1
 
     def _up(self, t: torch.Tensor):
         d = t.contiguous().to(self.device)
