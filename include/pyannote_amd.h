@@ -48,10 +48,10 @@ size_t pa_prof_report(char* buf, size_t cap);
 typedef struct pa_seg_weights {
   int32_t sinc_stride;   /* 10 */
   int32_t lstm_layers;   /* L */
-  int32_t lstm_hidden;   /* 128 (only value built) */
-  int32_t lstm_bidir;    /* 1 */
+  int32_t lstm_hidden;   /* multiple of 16 (32 when unidirectional), <= 512; 128 + bidirectional = register-resident kernel */
+  int32_t lstm_bidir;    /* 1 / 0 */
   int32_t num_linear;    /* 0..PA_MAX_LINEAR */
-  int32_t linear_hidden; /* 128 */
+  int32_t linear_hidden; /* multiple of 32 */
   int32_t num_classes;   /* powerset classes (7) */
   int32_t num_speakers;  /* multilabel width (3) */
   float wav_gamma, wav_beta;  /* sincnet.wav_norm1d.{weight,bias} */
@@ -63,9 +63,11 @@ typedef struct pa_seg_weights {
   const float* conv2_w;   /* [4][75][64]  image of sincnet.conv1d.2.weight (60,60,5) */
   const float* conv2_b;   /* [64] */
   const float* norm2;     /* [2][60] */
-  const float* lstm_wih[PA_MAX_LSTM_LAYERS];  /* [1024][Kin] rows permuted, Kin = 64 (layer 0) / 256 */
-  const float* lstm_bias[PA_MAX_LSTM_LAYERS]; /* [1024] b_ih + b_hh, permuted */
-  const float* lstm_whh[PA_MAX_LSTM_LAYERS];  /* [2][4][8][32][64] MFMA B image of weight_hh */
+  const float* lstm_wih[PA_MAX_LSTM_LAYERS];  /* [ndir * 4H][Kin] rows permuted (pa_lstm_rec / pa_lstm_rec_h column
+                                               * order), Kin = 64 (layer 0) / ndir * H */
+  const float* lstm_bias[PA_MAX_LSTM_LAYERS]; /* [ndir * 4H] b_ih + b_hh, permuted */
+  const float* lstm_whh[PA_MAX_LSTM_LAYERS];  /* MFMA B image of weight_hh: [2][4][8][32][64] (H = 128, bidirectional)
+                                               * or the layout of pa_lstm_rec_h */
   const float* lin_w[PA_MAX_LINEAR];          /* [out][in] as torch */
   const float* lin_b[PA_MAX_LINEAR];
   const float* cls_w;                         /* [num_classes][in] */
@@ -121,6 +123,13 @@ int pa_gemm_tn_s2(const float* X, int B, int H, int W, int cin, const float* Wt,
                   long ldc, int N, void* stream);
 int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T,
                 void* stream);
+/* the recurrence for any hidden size H (multiple of 16, <= 512) and ndir in {1, 2} (PyanNet.py:64-72 accepts any
+ * nn.LSTM configuration).  H == 128 && ndir == 2: pa_lstm_rec with its operand layouts.  Otherwise
+ *   xproj : [tile][t][ndir * 4H][16], column dir * 4H + (4 u + q) * 16 + n  <->  torch gate row q H + 16 u + n (q: i,f,g,o)
+ *   whh   : [dir][u][q][k4][lane][j] = weight_hh[q H + 16 u + (lane & 15)][16 k4 + 4 j + (lane >> 4)]
+ *   out   : [m][ndir * H], m = (tile * T + t) * 16 + b16, columns dir * H + j */
+int pa_lstm_rec_h(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T, int H,
+                  void* stream);
 int pa_classifier(const float* X, int ldx, int K, int ntiles, int T, int B, const float* cw,
                   const float* cb, int NC, const unsigned char* mapping, int S, float* logp,
                   unsigned char* multilabel, void* stream);

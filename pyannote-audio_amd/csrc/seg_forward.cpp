@@ -66,11 +66,16 @@ bool make_plan(const pa_seg_weights* w, int B, int N, int64_t chunk_stride, SegP
   p->st3m = take((size_t)B * 60);
   p->st3r = take((size_t)B * 60);
   p->x0 = take((size_t)p->M * 64);
-  p->xproj = take((size_t)p->M * 1024);
-  p->h0 = take((size_t)p->M * 256);
-  p->h1 = take((size_t)p->M * 256);
-  p->l0 = take((size_t)p->M * 128);
-  p->l1 = take((size_t)p->M * 128);
+  {
+    // gate pre-activations (ndir * 4H columns), two layer outputs (ndir * H), two head activations
+    const size_t nd = w->lstm_bidir ? 2 : 1, Hh = (size_t)w->lstm_hidden;
+    const size_t lw = w->num_linear > 0 ? (size_t)w->linear_hidden : 0;
+    p->xproj = take((size_t)p->M * nd * 4 * Hh);
+    p->h0 = take((size_t)p->M * nd * Hh);
+    p->h1 = take((size_t)p->M * nd * Hh);
+    p->l0 = take((size_t)p->M * lw);
+    p->l1 = take((size_t)p->M * lw);
+  }
   p->span = p->span_pos = 0;
   p->span_s = p->tap_sums = 0;
   if (shared_sinc_wanted(w, B, N, chunk_stride)) {
@@ -122,10 +127,12 @@ int pa_seg_forward(const pa_seg_weights* w, const float* wav, int64_t wav_len, i
     // a workspace sized without the stride (pa_seg_workspace_bytes): the per-chunk sinc layer
     make_plan(w, num_chunks, num_samples, num_samples, &p);
   }
-  if (w->lstm_hidden != 128 || !w->lstm_bidir || w->lstm_layers < 1 ||
+  if (w->lstm_hidden < 16 || w->lstm_hidden % 16 != 0 || w->lstm_hidden > 512 ||
+      (!w->lstm_bidir && w->lstm_hidden % 32 != 0) || w->lstm_layers < 1 ||
       w->lstm_layers > PA_MAX_LSTM_LAYERS || w->num_linear > PA_MAX_LINEAR ||
-      (w->num_linear > 0 && w->linear_hidden != 128)) {
-    pa::set_error("pa_seg_forward: only bidirectional LSTM(128) + Linear(128) stacks are built");
+      (w->num_linear > 0 && (w->linear_hidden < 32 || w->linear_hidden % 32 != 0))) {
+    pa::set_error("pa_seg_forward: LSTM hidden size must be a multiple of 16 (32 when unidirectional) up to 512, "
+                  "Linear widths multiples of 32 (got %d, %d)", w->lstm_hidden, w->linear_hidden);
     return 3;
   }
   if (workspace_bytes < p.total * sizeof(float)) {
@@ -170,20 +177,21 @@ int pa_seg_forward(const pa_seg_weights* w, const float* wav, int64_t wav_len, i
   const float* in = ws + p.x0;
   int kin = 64;
   float* hbuf[2] = {ws + p.h0, ws + p.h1};
+  const int ndir = w->lstm_bidir ? 2 : 1, Hh = w->lstm_hidden;
   for (int l = 0; l < w->lstm_layers; ++l) {
-    RUN(pa_gemm_tn(in, kin, w->lstm_wih[l], kin, w->lstm_bias[l], ws + p.xproj, 0, (int)p.M, 1024, kin,
+    RUN(pa_gemm_tn(in, kin, w->lstm_wih[l], kin, w->lstm_bias[l], ws + p.xproj, 0, (int)p.M, ndir * 4 * Hh, kin,
                    0, 1, stream));
-    RUN(pa_lstm_rec(ws + p.xproj, w->lstm_whh[l], hbuf[l & 1], p.ntiles, 2, p.T, stream));
+    RUN(pa_lstm_rec_h(ws + p.xproj, w->lstm_whh[l], hbuf[l & 1], p.ntiles, ndir, p.T, Hh, stream));
     in = hbuf[l & 1];
-    kin = 256;
+    kin = ndir * Hh;
   }
   // feed-forward head (PyanNet.py:236-240)
   float* lbuf[2] = {ws + p.l0, ws + p.l1};
   for (int l = 0; l < w->num_linear; ++l) {
-    RUN(pa_gemm_tn(in, kin, w->lin_w[l], kin, w->lin_b[l], lbuf[l & 1], 128, (int)p.M, 128, kin, 1, 0,
-                   stream));
+    RUN(pa_gemm_tn(in, kin, w->lin_w[l], kin, w->lin_b[l], lbuf[l & 1], w->linear_hidden, (int)p.M,
+                   w->linear_hidden, kin, 1, 0, stream));
     in = lbuf[l & 1];
-    kin = 128;
+    kin = w->linear_hidden;
   }
   RUN(pa_classifier(in, kin, kin, p.ntiles, p.T, B, w->cls_w, w->cls_b, w->num_classes,
                     w->powerset_map, w->num_speakers, logp, multilabel, stream));

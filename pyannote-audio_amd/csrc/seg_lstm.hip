@@ -8,6 +8,8 @@
 //                 256 KB) lives in the register file of the CU for the whole sequence: 4 waves x 256
 //                 VGPRs as MFMA B operands; h_t goes through a double-buffered 16x128 LDS tile; the
 //                 cell state never leaves registers.  589 dependent steps, one barrier per step.
+//   k_lstm_rec_gen  the recurrence for any other hidden size (multiple of 16) / a single direction: W_hh streamed
+//                 from L2 as MFMA operands, two 16-chunk tiles per workgroup.
 //   k_classifier  Linear(K -> NC) + log-softmax + powerset arg-max -> multilabel LUT; or, for multi-label
 //                 (non-powerset) checkpoints, Linear(K -> NC) + sigmoid (core/model.py:271-299).
 //
@@ -263,6 +265,106 @@ __global__ __launch_bounds__(256, 1) void k_lstm_rec(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------
+// LSTM recurrence, any hidden size H that is a multiple of 16 (<= 512), one or two directions
+// (PyanNet.py:64-72, 98-123 accept any nn.LSTM configuration; the register-resident kernel above is the
+// H = 128 bidirectional special case).  grid = (ceil(ntiles / MT), ndir), block = 256.
+//   W_hh (4H x H) no longer fits a CU's register file in general (H = 256: 1 MB): it is STREAMED from L2 every
+//   step as MFMA B operands, and a workgroup owns MT = 2 tiles of 16 chunks so that every streamed operand feeds
+//   two MFMAs (H = 256: 2 048 MFMAs ~ 27 us against ~7 us of L2 traffic per step).
+//   A wave owns the hidden units of the 16-unit tiles u = w, w + 4, ...; per unit tile the four gates are four
+//   16 x 16 accumulators per chunk tile.
+//   xproj : [tile][t][ndir * 4H][16], column dir * 4H + (4 u + q) * 16 + n  <->  torch gate row q H + 16 u + n
+//   whh_g : [dir][u][q][k4][lane][j]  =  W_hh[q H + 16 u + (lane & 15)][16 k4 + 4 j + (lane >> 4)]
+//   out   : [m][ndir * H], m = (tile * T + t) * 16 + b16, columns dir * H + j
+// ---------------------------------------------------------------------------------------------
+constexpr int LSTMG_MT = 2;
+constexpr int LSTMG_MAXU = 8;    // unit tiles per wave: H <= 16 * 4 * 8 = 512
+
+__global__ __launch_bounds__(256) void k_lstm_rec_gen(const float* __restrict__ xproj,
+                                                      const float* __restrict__ whh_g,
+                                                      float* __restrict__ out, int T, int H, int ntiles,
+                                                      int ndir, int hstride) {
+  extern __shared__ float hsg[];   // [MT][2][16][hstride], hstride = 4 (mod 64): conflict-free reads and writes
+  constexpr int MT = LSTMG_MT;
+  const int tile0 = blockIdx.x * MT, dir = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int U = H >> 4, K4 = H >> 4;
+  const long NG = (long)ndir * 4 * H;
+  const int ldo = ndir * H;
+  for (int i = tid; i < MT * 2 * 16 * hstride; i += 256) hsg[i] = 0.f;
+  f32x4 c[LSTMG_MAXU][MT];
+#pragma unroll
+  for (int ui = 0; ui < LSTMG_MAXU; ++ui)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) c[ui][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  // a tile beyond the last one (odd ntiles) is computed on the last tile's inputs and never stored
+  int tl[MT];
+  bool live[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    live[mt] = tile0 + mt < ntiles;
+    tl[mt] = live[mt] ? tile0 + mt : ntiles - 1;
+  }
+  int cur = 0;
+#pragma unroll 1
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? T - 1 - step : step;
+#pragma unroll
+    for (int ui = 0; ui < LSTMG_MAXU; ++ui) {
+      const int u = w + 4 * ui;
+      if (u >= U) break;
+      f32x4 xin[MT][4], acc[MT][4];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          xin[mt][q] = *reinterpret_cast<const f32x4*>(
+              xproj + (((long)tl[mt] * T + t) * NG + (long)dir * 4 * H + (4 * u + q) * 16 + n) * 16 + 4 * g);
+          acc[mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      const f32x4* wp = reinterpret_cast<const f32x4*>(whh_g) + ((long)(dir * U + u) * 4 * K4) * 64 + lane;
+      const float* hp0 = hsg + (cur * 16 + n) * hstride + g;
+#pragma unroll 2
+      for (int k4 = 0; k4 < K4; ++k4) {
+        f32x4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = wp[(long)(q * K4 + k4) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float a = hp0[mt * 2 * 16 * hstride + 16 * k4 + 4 * j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[mt][q] = MFMA16(a, b[q][j], acc[mt][q]);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float* hn = hsg + ((mt * 2 + (cur ^ 1)) * 16 + 4 * g) * hstride + 16 * u + n;
+        float* op = out + (((long)tl[mt] * T + t) * 16 + 4 * g) * ldo + dir * H + 16 * u + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ig = sigmoidf_(acc[mt][0][r] + xin[mt][0][r]);
+          const float fg = sigmoidf_(acc[mt][1][r] + xin[mt][1][r]);
+          const float gg = tanhf_(acc[mt][2][r] + xin[mt][2][r]);
+          const float og = sigmoidf_(acc[mt][3][r] + xin[mt][3][r]);
+          const float cn = fg * c[ui][mt][r] + ig * gg;
+          c[ui][mt][r] = cn;
+          const float h = og * tanhf_(cn);
+          hn[r * hstride] = h;
+          if (live[mt]) op[(long)r * ldo] = h;
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // classifier Linear(K -> NC) + log-softmax + hard powerset -> multilabel
 // (PyanNet.py:240, core/model.py:290-291, utils/powerset.py:115-140).  One thread per row.
 // ---------------------------------------------------------------------------------------------
@@ -427,6 +529,23 @@ int pa_lstm_rec(const float* xproj, const float* whh_packed, float* out, int nti
   hipLaunchKernelGGL(pa::k_lstm_rec, dim3(ntiles, ndir), dim3(256), 0, (hipStream_t)stream, xproj,
                      whh_packed, out, T);
   PA_CHECK_LAUNCH("pa_lstm_rec");
+  return 0;
+}
+
+int pa_lstm_rec_h(const float* xproj, const float* whh_packed, float* out, int ntiles, int ndir, int T, int H,
+                  void* stream) {
+  if (ntiles <= 0 || T <= 0) return 0;
+  if (H == 128 && ndir == 2) return pa_lstm_rec(xproj, whh_packed, out, ntiles, ndir, T, stream);
+  PA_REQUIRE(H >= 16 && H % 16 == 0 && H <= 64 * pa::LSTMG_MAXU && (ndir == 1 || ndir == 2),
+             "pa_lstm_rec_h: hidden size %d must be a multiple of 16 in [16, %d], directions 1 or 2 (got %d)", H,
+             64 * pa::LSTMG_MAXU, ndir);
+  const int hstride = ((H + 63) / 64) * 64 + 4;
+  const size_t lds = sizeof(float) * pa::LSTMG_MT * 2 * 16 * hstride;
+  pa::ProfScope prof("k_lstm_rec_gen", stream, 2.0 * ntiles * 16 * ndir * T * H * 4.0 * H,
+                     4.0 * ntiles * 16 * ndir * T * (4.0 * H + H));
+  hipLaunchKernelGGL(pa::k_lstm_rec_gen, dim3(pa::cdiv(ntiles, pa::LSTMG_MT), ndir), dim3(256), lds,
+                     (hipStream_t)stream, xproj, whh_packed, out, T, H, ntiles, ndir, hstride);
+  PA_CHECK_LAUNCH("pa_lstm_rec_h");
   return 0;
 }
 

@@ -94,11 +94,16 @@ bool make_plan(const pa_sser_weights* w, int B, int N, SserPlan* p) {
   p->h = take((size_t)p->M * F);
   p->acc = take((size_t)p->M * D);
   p->x0 = take((size_t)p->Ml * D);
-  p->xproj = take((size_t)p->Ml * 1024);
-  p->h0 = take((size_t)p->Ml * 256);
-  p->h1 = take((size_t)p->Ml * 256);
-  p->l0 = take((size_t)p->Ml * 128);
-  p->l1 = take((size_t)p->Ml * 128);
+  {
+    // gate pre-activations (ndir * 4H columns), two layer outputs (ndir * H), two head activations
+    const size_t nd = w->lstm_bidir ? 2 : 1, Hh = (size_t)w->lstm_hidden;
+    const size_t lw = w->num_linear > 0 ? (size_t)w->linear_hidden : 0;
+    p->xproj = take((size_t)p->Ml * nd * 4 * Hh);
+    p->h0 = take((size_t)p->Ml * nd * Hh);
+    p->h1 = take((size_t)p->Ml * nd * Hh);
+    p->l0 = take((size_t)p->Ml * lw);
+    p->l1 = take((size_t)p->Ml * lw);
+  }
   p->total = o;
   return true;
 }
@@ -134,9 +139,12 @@ int pa_sser_forward(const pa_sser_weights* w, const float* wav, int64_t wav_len,
                   "needs its relative position table");
     return 3;
   }
-  if (w->lstm_hidden != 128 || !w->lstm_bidir || w->lstm_layers < 1 || w->lstm_layers > PA_MAX_LSTM_LAYERS ||
-      w->num_linear > PA_MAX_LINEAR || (w->num_linear > 0 && w->linear_hidden != 128)) {
-    pa::set_error("pa_sser_forward: only bidirectional LSTM(128) + Linear(128) stacks are built");
+  if (w->lstm_hidden < 16 || w->lstm_hidden % 16 != 0 || w->lstm_hidden > 512 ||
+      (!w->lstm_bidir && w->lstm_hidden % 32 != 0) || w->lstm_layers < 1 ||
+      w->lstm_layers > PA_MAX_LSTM_LAYERS || w->num_linear > PA_MAX_LINEAR ||
+      (w->num_linear > 0 && (w->linear_hidden < 32 || w->linear_hidden % 32 != 0))) {
+    pa::set_error("pa_sser_forward: LSTM hidden size must be a multiple of 16 (32 when unidirectional) up to 512, "
+                  "Linear widths multiples of 32 (got %d, %d)", w->lstm_hidden, w->linear_hidden);
     return 3;
   }
   if (workspace_bytes < p.total * sizeof(float)) {
@@ -245,18 +253,20 @@ int pa_sser_forward(const pa_sser_weights* w, const float* wav, int64_t wav_len,
   const float* in = ws + p.x0;
   int kin = D;
   float* hbuf[2] = {ws + p.h0, ws + p.h1};
+  const int ndir = w->lstm_bidir ? 2 : 1, Hh = w->lstm_hidden;
   for (int l = 0; l < w->lstm_layers; ++l) {
-    RUN(pa_gemm_tn(in, kin, w->lstm_wih[l], kin, w->lstm_bias[l], ws + p.xproj, 0, (int)p.Ml, 1024, kin, 0, 1,
-                   stream));
-    RUN(pa_lstm_rec(ws + p.xproj, w->lstm_whh[l], hbuf[l & 1], p.ntiles, 2, T, stream));
+    RUN(pa_gemm_tn(in, kin, w->lstm_wih[l], kin, w->lstm_bias[l], ws + p.xproj, 0, (int)p.Ml, ndir * 4 * Hh, kin, 0,
+                   1, stream));
+    RUN(pa_lstm_rec_h(ws + p.xproj, w->lstm_whh[l], hbuf[l & 1], p.ntiles, ndir, T, Hh, stream));
     in = hbuf[l & 1];
-    kin = 256;
+    kin = ndir * Hh;
   }
   float* lbuf[2] = {ws + p.l0, ws + p.l1};
   for (int l = 0; l < w->num_linear; ++l) {
-    RUN(pa_gemm_tn(in, kin, w->lin_w[l], kin, w->lin_b[l], lbuf[l & 1], 128, (int)p.Ml, 128, kin, 1, 0, stream));
+    RUN(pa_gemm_tn(in, kin, w->lin_w[l], kin, w->lin_b[l], lbuf[l & 1], w->linear_hidden, (int)p.Ml,
+                   w->linear_hidden, kin, 1, 0, stream));
     in = lbuf[l & 1];
-    kin = 128;
+    kin = w->linear_hidden;
   }
   RUN(pa_classifier(in, kin, kin, p.ntiles, T, B, w->cls_w, w->cls_b, w->num_classes, w->powerset_map,
                     w->num_speakers, logp, multilabel, stream));

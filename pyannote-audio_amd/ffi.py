@@ -171,6 +171,7 @@ _OPTIONAL: list[tuple] = [
     ("pa_emb_calibrate_workspace_bytes", [C.POINTER(EmbWeights), C.c_int, C.c_int], C.c_size_t),
     ("pa_emb_calibrate_winograd", [C.POINTER(EmbWeights), c_fp, C.c_int64, C.c_int64, C.c_int, C.c_int, c_fp, c_fp,
                                    c_fp, C.c_size_t, c_fp], C.c_int),
+    ("pa_lstm_rec_h", [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp], C.c_int),
     ("pa_absmax_diff", [c_fp, c_fp, C.c_long, c_fp, c_fp], C.c_int),
     ("pa_gemm_tn_s2", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp, C.c_long, C.c_int,
                        c_fp], C.c_int),

@@ -105,16 +105,15 @@ class SegmentationPack:
         lstm = {"hidden_size": 128, "num_layers": 2, "bidirectional": True, "monolithic": True,
                 **(hparams.get("lstm") or {})}
         linear = {"hidden_size": 128, "num_layers": 2, **(hparams.get("linear") or {})}
-        if sinc["stride"] != 10 or lstm["hidden_size"] != 128 or not lstm["bidirectional"]:
-            raise NotImplementedError("kernels are built for SincNet stride 10 and bi-LSTM(128)")
-        if linear["num_layers"] > 0 and linear["hidden_size"] != 128:
-            raise NotImplementedError("kernels are built for Linear(128) heads")
+        if sinc["stride"] != 10:
+            raise NotImplementedError("kernels are built for SincNet stride 10")
+        H, ndir, lw = lstm_geometry(lstm, linear)
         self.device = device
         self._keep: list[torch.Tensor] = []
         w = ffi.SegWeights()
         w.lstm_layers = L = int(lstm["num_layers"])
-        w.lstm_hidden, w.lstm_bidir = 128, 1
-        w.num_linear, w.linear_hidden = int(linear["num_layers"]), 128
+        w.lstm_hidden, w.lstm_bidir = H, int(ndir == 2)
+        w.num_linear, w.linear_hidden = int(linear["num_layers"]), lw
         w.num_classes, w.num_speakers = num_classes, num_speakers
         self.sinc_taps = pack_sincnet(sd, w, self._up)  # (80, 251) kept for tests
 
@@ -137,25 +136,64 @@ class SegmentationPack:
         return C.c_void_p(d.data_ptr())
 
 
+def _lstm_row_perm_gen(H: int) -> torch.Tensor:
+    """pa_lstm_rec_h: perm[(4 u + q) * 16 + n] = torch gate row q H + 16 u + n"""
+    u = torch.arange(H // 16).view(-1, 1, 1)
+    q = torch.arange(4).view(1, 4, 1)
+    n = torch.arange(16).view(1, 1, 16)
+    return (q * H + 16 * u + n).reshape(-1)
+
+
+def _lstm_whh_image_gen(whh: torch.Tensor) -> torch.Tensor:
+    """(4H, H) weight_hh -> [u][q][k4][lane][j] = W[q H + 16 u + (lane & 15)][16 k4 + 4 j + (lane >> 4)]
+    (the operand stream of k_lstm_rec_gen, csrc/seg_lstm.hip)"""
+    H = whh.shape[1]
+    u = torch.arange(H // 16).view(-1, 1, 1, 1, 1)
+    q = torch.arange(4).view(1, 4, 1, 1, 1)
+    k4 = torch.arange(H // 16).view(1, 1, -1, 1, 1)
+    lane = torch.arange(64).view(1, 1, 1, 64, 1)
+    j = torch.arange(4).view(1, 1, 1, 1, 4)
+    rows = q * H + 16 * u + (lane & 15)
+    cols = 16 * k4 + 4 * j + (lane >> 4)
+    rows, cols = torch.broadcast_tensors(rows, cols)
+    return whh[rows, cols].contiguous().view(-1)
+
+
+def lstm_geometry(lstm: dict, linear: dict) -> tuple:
+    """(hidden size, directions, linear width) the kernels run, or NotImplementedError naming the constraint
+    (PyanNet.py:64-72 / SSeRiouSS.py:141-170 accept any nn.LSTM / Linear configuration)"""
+    H, bidir = int(lstm["hidden_size"]), bool(lstm["bidirectional"])
+    if H < 16 or H % 16 or H > 512 or (not bidir and H % 32):
+        raise NotImplementedError(f"LSTM hidden size {H}: the kernels need a multiple of 16 (32 when "
+                                  "unidirectional) up to 512")
+    lw = int(linear["hidden_size"])
+    if int(linear["num_layers"]) > 0 and (lw < 32 or lw % 32):
+        raise NotImplementedError(f"Linear width {lw}: the kernels need a multiple of 32")
+    return H, 2 if bidir else 1, lw
+
+
 def pack_lstm_head(sd: dict, w, lstm: dict, up):
     """bi-LSTM stack (PyTorch gate order i, f, g, o; monolithic `lstm.weight_ih_l{k}` or split
     `lstm.{k}.weight_ih_l0` keys, PyanNet.py:98-123 / SSeRiouSS.py:141-170), Linear head and classifier ->
     the operand images shared by pa_seg_weights and pa_sser_weights."""
     L = int(lstm["num_layers"])
-    perm = _lstm_row_perm()
+    H, ndir = int(w.lstm_hidden), 2 if w.lstm_bidir else 1
+    fast = H == 128 and ndir == 2          # the register-resident kernel and its operand layouts
+    perm = _lstm_row_perm() if fast else _lstm_row_perm_gen(H)
+    image = _lstm_whh_image if fast else _lstm_whh_image_gen
     for l in range(L):
         if lstm["monolithic"]:
             key = lambda name, rev: f"lstm.{name}_l{l}" + ("_reverse" if rev else "")
         else:
             key = lambda name, rev: f"lstm.{l}.{name}_l0" + ("_reverse" if rev else "")
         wih, bias, whh = [], [], []
-        for rev in (False, True):
+        for rev in (False, True)[:ndir]:
             wi = sd[key("weight_ih", rev)][perm]
-            if wi.shape[1] == 60:
-                wi = torch.nn.functional.pad(wi, (0, 4))
+            if wi.shape[1] % 32:            # (layer 0 of PyanNet: 60 SincNet channels -> the GEMM's K = 64)
+                wi = torch.nn.functional.pad(wi, (0, 32 - wi.shape[1] % 32))
             wih.append(wi)
             bias.append((sd[key("bias_ih", rev)] + sd[key("bias_hh", rev)])[perm])
-            whh.append(_lstm_whh_image(sd[key("weight_hh", rev)]))
+            whh.append(image(sd[key("weight_hh", rev)]))
         w.lstm_wih[l] = up(torch.cat(wih, 0)).value
         w.lstm_bias[l] = up(torch.cat(bias, 0)).value
         w.lstm_whh[l] = up(torch.cat(whh, 0)).value
@@ -252,10 +290,7 @@ class SSeRiouSSPack:
         lstm = {"hidden_size": 128, "num_layers": 4, "bidirectional": True, "monolithic": True,
                 **(hparams.get("lstm") or {})}
         linear = {"hidden_size": 128, "num_layers": 2, **(hparams.get("linear") or {})}
-        if lstm["hidden_size"] != 128 or not lstm["bidirectional"]:
-            raise NotImplementedError("kernels are built for bi-LSTM(128)")
-        if linear["num_layers"] > 0 and linear["hidden_size"] != 128:
-            raise NotImplementedError("kernels are built for Linear(128) heads")
+        H, ndir, lw = lstm_geometry(lstm, linear)
         self.device = device
         self.cfg = cfg
         self._keep: list[torch.Tensor] = []
@@ -340,8 +375,8 @@ class SSeRiouSSPack:
             for i in range(nl):
                 w.layer_mix[i] = float(mix[i])
         w.lstm_layers = int(lstm["num_layers"])
-        w.lstm_hidden, w.lstm_bidir = 128, 1
-        w.num_linear, w.linear_hidden = int(linear["num_layers"]), 128
+        w.lstm_hidden, w.lstm_bidir = H, int(ndir == 2)
+        w.num_linear, w.linear_hidden = int(linear["num_layers"]), lw
         w.num_classes, w.num_speakers = num_classes, num_speakers
         pack_lstm_head(sd, w, lstm, up)
         self.powerset = bool(max_set_size)

@@ -315,7 +315,7 @@ def _emulate_sser_encoder(pack, wav):
         for j in range(KW):
             pos[:, :, g * CG:(g + 1) * CG] += xp[:, j:j + T, g * CG:(g + 1) * CG] @ w3[g, j]
     x = x + F.gelu(pos + _host_array(w.pos_b, D))
-    if w.layer_norm_first:
+    if not w.layer_norm_first:      # (post-LN: the encoder-level LayerNorm precedes the layers, sser_forward.cpp)
         x = F.layer_norm(x, (D,), _host_array(w.enc_ln_g, D), _host_array(w.enc_ln_b, D))
     bias = pack.relative_bias(T)
     outs = []

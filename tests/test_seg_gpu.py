@@ -223,3 +223,75 @@ def test_shared_sinc_layer_matches_the_per_chunk_layer(seg, gpu_device):
     decided = (top2[..., 0] - top2[..., 1]) > 1e-4
     same = (outs["1"][1] == outs["0"][1]).all(dim=-1)
     assert bool((same | ~decided).all())
+
+
+@pytest.mark.parametrize("lstm,linear", [
+    ({"hidden_size": 64, "num_layers": 2}, {"hidden_size": 64, "num_layers": 2}),
+    ({"hidden_size": 256, "num_layers": 2}, {"hidden_size": 256, "num_layers": 1}),
+    ({"hidden_size": 96, "num_layers": 1}, {"hidden_size": 128, "num_layers": 0}),
+    ({"hidden_size": 64, "num_layers": 2, "bidirectional": False, "monolithic": False}, {"hidden_size": 96, "num_layers": 2}),
+    ({"hidden_size": 128, "num_layers": 1, "bidirectional": False}, {"hidden_size": 32, "num_layers": 1}),
+])
+def test_other_lstm_and_linear_widths_match_oracle(gpu_device, lstm, linear):
+    """PyanNet.py:64-72, 98-123 accept any nn.LSTM / Linear configuration: hidden sizes
+    other than 128, a single direction, split (non-monolithic) stacks, heads of other widths or none at all run
+    through k_lstm_rec_gen (W_hh streamed from L2, two 16-chunk tiles per workgroup; csrc/seg_lstm.hip) and the
+    same GEMM / classifier kernels -- log-probabilities against the torch-CPU oracle, 37 chunks (an odd number of
+    tiles: the last workgroup owns a single one)."""
+    from oracle.models import PyanNet
+    from pyannote_audio_amd.weights import SegmentationPack
+    from pyannote_audio_amd.segmentation import SegmentationEngine
+    torch.manual_seed(77)
+    model = PyanNet(num_classes=7, lstm=lstm, linear=linear).eval()
+    pack = SegmentationPack(model.state_dict(), {"lstm": lstm, "linear": linear}, 7, 3, 2, gpu_device)
+    assert pack.struct.lstm_hidden == lstm["hidden_size"]
+    eng = SegmentationEngine(pack)
+    B, N, stride = 37, 32000, 4000
+    wav = _wave(1, stride * (B - 1) + N, seed=11).view(-1)
+    chunks = torch.stack([wav[b * stride: b * stride + N] for b in range(B)]).unsqueeze(1)
+    with torch.inference_mode():
+        ref = model(chunks)
+    logp, ml = eng.forward_strided(wav.to(gpu_device), stride, B, N)
+    torch.cuda.synchronize()
+    assert logp.shape == ref.shape
+    tag = "seg_H%d_%s_lin%dx%d" % (lstm["hidden_size"], "uni" if lstm.get("bidirectional") is False else "bi",
+                                   linear["hidden_size"], linear["num_layers"])
+    assert north_star_ratio(tag, logp, ref) <= 1.0
+    top2 = ref.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert torch.equal(logp.cpu().argmax(-1)[safe], ref.argmax(-1)[safe])
+
+
+def test_lstm_recurrence_any_width_through_the_c_abi(gpu_device):
+    """pa_lstm_rec_h directly: one bidirectional layer of H = 48 / 192 / 512 and a unidirectional one of H = 32 on
+    random gate inputs vs torch.nn.LSTM (W_ih = identity block: the test feeds the gate pre-activations itself)."""
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.weights import _lstm_row_perm_gen, _lstm_whh_image_gen
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(9)
+    for H, ndir, B, T in ((48, 2, 20, 23), (192, 2, 33, 11), (512, 2, 16, 5), (32, 1, 50, 40)):
+        K = 32
+        ref_lstm = torch.nn.LSTM(K, H, 1, bidirectional=ndir == 2, batch_first=True)
+        x = torch.randn(B, T, K, generator=g)
+        with torch.inference_mode():
+            ref, _ = ref_lstm(x)
+        sd = ref_lstm.state_dict()
+        perm = _lstm_row_perm_gen(H)
+        ntiles = (B + 15) // 16
+        # gate pre-activations x W_ih^T + b_ih + b_hh in the kernel's layout [tile][t][ndir * 4H][16]
+        xproj = torch.zeros(ntiles, T, ndir * 4 * H, 16)
+        whh = []
+        for d in range(ndir):
+            sfx = "_reverse" if d else ""
+            pre = x @ sd["weight_ih_l0" + sfx].T + sd["bias_ih_l0" + sfx] + sd["bias_hh_l0" + sfx]   # (B, T, 4H)
+            pre = pre[..., perm]
+            for b in range(B):
+                xproj[b // 16, :, d * 4 * H:(d + 1) * 4 * H, b % 16] = pre[b]
+            whh.append(_lstm_whh_image_gen(sd["weight_hh_l0" + sfx]))
+        xd, wd = xproj.to(gpu_device), torch.cat(whh).to(gpu_device)
+        out = torch.full((ntiles * T * 16, ndir * H), float("nan"), device=gpu_device)
+        ffi.check(lib.pa_lstm_rec_h(ffi.ptr(xd), ffi.ptr(wd), ffi.ptr(out), ntiles, ndir, T, H, ffi.stream()),
+                  "pa_lstm_rec_h")
+        torch.cuda.synchronize()
+        got = out.view(ntiles, T, 16, ndir * H).permute(0, 2, 1, 3).reshape(ntiles * 16, T, ndir * H)[:B].cpu()
+        assert north_star_ratio(f"lstm_rec_h_H{H}_d{ndir}", got, ref) <= 1.0
