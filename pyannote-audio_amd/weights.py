@@ -290,7 +290,7 @@ class SSeRiouSSPack:
         lstm = {"hidden_size": 128, "num_layers": 4, "bidirectional": True, "monolithic": True,
                 **(hparams.get("lstm") or {})}
         linear = {"hidden_size": 128, "num_layers": 2, **(hparams.get("linear") or {})}
-        H, ndir, lw = lstm_geometry(lstm, linear)
+        lstm_h, lstm_dirs, lin_w = lstm_geometry(lstm, linear)
         self.device = device
         self.cfg = cfg
         self._keep: list[torch.Tensor] = []
@@ -375,8 +375,8 @@ class SSeRiouSSPack:
             for i in range(nl):
                 w.layer_mix[i] = float(mix[i])
         w.lstm_layers = int(lstm["num_layers"])
-        w.lstm_hidden, w.lstm_bidir = H, int(ndir == 2)
-        w.num_linear, w.linear_hidden = int(linear["num_layers"]), lw
+        w.lstm_hidden, w.lstm_bidir = lstm_h, int(lstm_dirs == 2)
+        w.num_linear, w.linear_hidden = int(linear["num_layers"]), lin_w
         w.num_classes, w.num_speakers = num_classes, num_speakers
         pack_lstm_head(sd, w, lstm, up)
         self.powerset = bool(max_set_size)

@@ -373,6 +373,7 @@ def test_sseriouss_pack_layouts(config, layer):
         model = om.seeded_sseriouss(wav2vec=wav2vec, num_layers=1, wav2vec_layer=layer)
     hparams = {"wav2vec": wav2vec, "wav2vec_layer": layer, "lstm": {"num_layers": 1}}
     pack = SSeRiouSSPack(model.state_dict(), hparams, 7, 3, 2, torch.device("cpu"))
+    assert (pack.struct.lstm_hidden, pack.struct.lstm_bidir, pack.struct.linear_hidden) == (128, 1, 128)
     g = torch.Generator().manual_seed(0)
     wav = (0.1 * torch.randn(2, 4000, generator=g)).clamp(-1, 1)
     with torch.inference_mode():
