@@ -233,6 +233,13 @@ int pa_winograd4_pack_host(const float* conv_weight /* (cout, cin, 3, 3), resnet
                            float* U_slabs /* HOST buffer, 36 * cout * cin floats */);
 int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                      const float* R, float* Y, int cout, int relu, void* stream);
+/* row ranges of one convolution (the maps X, R, Y are whole in every call): output rows 0 .. rows - 1 through F(4x4)
+ * (rows == H or a multiple of 4 below it) and rows y_first .. H - 1 through F(2x2) (y_first even).  pa_emb_forward
+ * splits a map whose height is 2 (mod 4) this way instead of padding its last F(4x4) tile row. */
+int pa_conv3x3_wino4_rows(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                          const float* R, float* Y, int cout, int relu, int rows, void* stream);
+int pa_conv3x3_wino_rows(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                         const float* R, float* Y, int cout, int relu, int y_first, void* stream);
 int pa_stats_pool(const float* feat, int B, int Fh, int Tp, int C, const float* masks, int S, int Fm,
                   const int* nearest_idx, float* stats, void* stream);
 

@@ -2,6 +2,7 @@
 // Replaces WeSpeakerResNet34.forward (wespeaker/__init__.py:324-343, resnet.py:399-430).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/pyannote_amd.h"
 
@@ -36,6 +37,14 @@ inline bool prefer_wino4(int H, int W, int cin) {
   // and 20 x 75 (1.11x) maps: the F(2x2) kernel does not reach its large-map rate on them either.
   const long gain = cin >= 256 ? 130 : 122;
   return p4 * 100 <= p2 * gain;
+}
+
+// OFF by default: measured neutral on MI355X (profiles/r5_row_split_ab.txt: per audio-hour k_conv3x3_wino4 417.0 ->
+// 395.7 ms, k_conv3x3_wino 161.5 -> 184.1 ms; step 793.8 / 802.2 vs 795.7 / 794.8 ms) -- the 2 x 128 tiles of the
+// F(2x2) kernel run the two-row strips at 2.25 ms per launch, exactly what the F(4x4) kernel saves.
+inline bool split_rows_wanted() {   // PA_EMB_SPLIT_ROWS=1 switches it on
+  static const bool on = getenv("PA_EMB_SPLIT_ROWS") != nullptr && atoi(getenv("PA_EMB_SPLIT_ROWS")) != 0;
+  return on;
 }
 
 bool make_plan(const pa_emb_weights* w, int B, int N, int S, EmbPlan* p, bool calib = false) {
@@ -168,6 +177,13 @@ static int emb_forward_impl(const pa_emb_weights* w, const float* wav, int64_t w
         if (r == 0) r = pa_absmax_diff(scratch, Y, n, rep + 2, stream);
       }
       return r;
+    }
+    if (v != nullptr && u != nullptr && H % 4 == 2 && H > 4 && split_rows_wanted() && prefer_wino4(H - 2, W, ci)) {
+      // a map whose height is 2 (mod 4) -- the 10-row maps of layer 4 on 10 s chunks -- would pad its last tile row
+      // half empty (12 rows of F(4x4) work for 10): F(4x4) on the rows above, the last two through the 2 x 128 tiles
+      // of the F(2x2) kernel (per useful pixel 1.29x the F(4x4) cost at 256 channels: 8 + 2.6 instead of 12)
+      const int r = pa_conv3x3_wino4_rows(X, B, H, W, ci, v, shift, R, Y, co, 1, H - 2, stream);
+      return r != 0 ? r : pa_conv3x3_wino_rows(X, B, H, W, ci, u, shift, R, Y, co, 1, H - 2, stream);
     }
     if (v != nullptr && prefer_wino4(H, W, ci)) return pa_conv3x3_wino4(X, B, H, W, ci, v, shift, R, Y, co, 1, stream);
     if (u != nullptr) return pa_conv3x3_wino(X, B, H, W, ci, u, shift, R, Y, co, 1, stream);

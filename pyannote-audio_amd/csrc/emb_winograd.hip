@@ -355,7 +355,8 @@ template <int TR, int TCG, bool HAS_R>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
-    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb, int* __restrict__ counters) {
+    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb, int y_first,
+    int* __restrict__ counters) {
   using G = WinoGeom<TR, TCG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
         wino_patch_lanes<TR, TCG>(prel, W, CIN, lane_v, slw, x0_last);
         wino_patch_bases<TR, TCG>(pbase, lane_v & 15, lane_v >> 4, wr, wc);
       }
-      const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb);
+      const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb, y_first);
       if (tid == 0) ahead = tq_claim_own(tq);
       for (int c0 = 0; c0 < CIN; c0 += WCB) {
         WINO_STAMP(0);
@@ -483,9 +484,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
 
 template <int TR, int TCG, bool HAS_R>
 static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
-                         const float* R, float* Y, int COUT, int relu, hipStream_t st) {
+                         const float* R, float* Y, int COUT, int relu, int y_first, hipStream_t st) {
   using G = WinoGeom<TR, TCG>;
-  const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H, 2 * TR);
+  const int tiles_w = cdiv(W, 32 * TCG), tiles_h = cdiv(H - y_first, 2 * TR);
   // + the claimed-tile mailbox (+ 16 KB of residual staging where it is used: k_conv3x3_wino RPRE)
   const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float) + 16 +
                      ((PA_WINO_RPRE && HAS_R && TCG == 1) ? 4 * 4096 : (PA_WINO_RTOUCH && HAS_R && TCG == 4 ? 4 * 256 : 0));
@@ -519,7 +520,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
     return 2;
   }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, tiles_w,
-                     tiles_hw, n_tiles, (int)total, (int)num_pb, counters);
+                     tiles_hw, n_tiles, (int)total, (int)num_pb, y_first, counters);
   return 0;
 }
 
@@ -670,9 +671,9 @@ static int launch_wino32(const float* X, int B, int H, int W, const float* U, co
 
 template <int TR, int TCG>
 static int launch_wino(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
-                       const float* R, float* Y, int COUT, int relu, hipStream_t st) {
-  return R != nullptr ? launch_wino_r<TR, TCG, true>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st)
-                      : launch_wino_r<TR, TCG, false>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, st);
+                       const float* R, float* Y, int COUT, int relu, int y_first, hipStream_t st) {
+  return R != nullptr ? launch_wino_r<TR, TCG, true>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, y_first, st)
+                      : launch_wino_r<TR, TCG, false>(X, B, H, W, CIN, U, shift, R, Y, COUT, relu, y_first, st);
 }
 
 }  // namespace pa
@@ -696,32 +697,44 @@ int pa_wino_read_stamps(unsigned long long* host, int zero) {
 // conv3x3, stride 1, pad 1, via Winograd F(2x2,3x3): Y = [relu](conv(X) + shift [+ R]).
 // U: G g G^T (BatchNorm scale folded) in the slab layout of weights.winograd_pack:
 // [cout/32][cin/16][row = 32 xi + n][slot][4], xi = 4a + b.
+int pa_conv3x3_wino_rows(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                         const float* R, float* Y, int cout, int relu, int y_first, void* stream);
+
 int pa_conv3x3_wino(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                     const float* R, float* Y, int cout, int relu, void* stream) {
-  if (B <= 0) return 0;
+  return pa_conv3x3_wino_rows(X, B, H, W, cin, U, shift, R, Y, cout, relu, 0, stream);
+}
+
+// the same convolution for the output rows y_first .. H - 1 only (y_first even; the rows above are somebody else's:
+// pa_emb_forward gives the last two rows of a map whose height is 2 (mod 4) to this kernel and the rest to F(4x4))
+int pa_conv3x3_wino_rows(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                         const float* R, float* Y, int cout, int relu, int y_first, void* stream) {
+  if (B <= 0 || y_first >= H) return 0;
+  PA_REQUIRE(y_first >= 0 && y_first % 2 == 0, "pa_conv3x3_wino_rows: y_first must be even and >= 0 (got %d)", y_first);
+  const int Hr = H - y_first;      // rows this launch covers
   PA_REQUIRE(cin % pa::WCB == 0 && cout % pa::W_BN == 0, "pa_conv3x3_wino: cin %% 16 and cout %% 32 required");
   PA_REQUIRE((long)H * W * (cin > cout ? cin : cout) * 4 < (1L << 28),
              "pa_conv3x3_wino: one image must be smaller than 256 MB");
   // `flops` = the direct convolution's (the reference's operation); the kernel executes 16/36 of them
-  pa::ProfScope prof("k_conv3x3_wino", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
-                     4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
+  pa::ProfScope prof("k_conv3x3_wino", stream, 2.0 * 9 * cin * cout * (double)B * Hr * W,
+                     4.0 * ((double)B * Hr * W * cin + (double)B * Hr * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
   // workgroup tile = 2*TR x 32*TCG output pixels: pick the shape that pads the map the least (10 s chunks:
   // 80/40 rows -> 8 x 32, 20 rows -> 4 x 64, 10 rows x 125 columns -> 2 x 128; the 38-column maps of 3 s
   // segments would waste 70 % of a 128-wide tile and take 4 x 64 instead); ties go to the taller tile,
   // whose halo is relatively smaller
   auto padded = [&](int tr, int tcg) {
-    return (long)pa::cdiv(H, 2 * tr) * 2 * tr * (long)pa::cdiv(W, 32 * tcg) * 32 * tcg;
+    return (long)pa::cdiv(Hr, 2 * tr) * 2 * tr * (long)pa::cdiv(W, 32 * tcg) * 32 * tcg;
   };
   const long a41 = padded(4, 1), a22 = padded(2, 2), a14 = padded(1, 4);
   static const bool wino32 = getenv("PA_WINO32") == nullptr || atoi(getenv("PA_WINO32")) != 0;   // A/B aid
-  if (wino32 && cin == 32 && cout == 32 && a41 <= a22 && a41 <= a14) {
+  if (wino32 && cin == 32 && cout == 32 && y_first == 0 && a41 <= a22 && a41 <= a14) {
     const int rc = R != nullptr ? pa::launch_wino32<true>(X, B, H, W, U, shift, R, Y, relu, st)
                                 : pa::launch_wino32<false>(X, B, H, W, U, shift, R, Y, relu, st);
     if (rc != 0) return rc;
-  } else if (a41 <= a22 && a41 <= a14) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
-  else if (a22 <= a14) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
-  else pa::launch_wino<1, 4>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  } else if (a41 <= a22 && a41 <= a14) pa::launch_wino<4, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, y_first, st);
+  else if (a22 <= a14) pa::launch_wino<2, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, y_first, st);
+  else pa::launch_wino<1, 4>(X, B, H, W, cin, U, shift, R, Y, cout, relu, y_first, st);
   PA_CHECK_LAUNCH("pa_conv3x3_wino");
   return 0;
 }

@@ -679,9 +679,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 
 template <bool HAS_R>
 static int launch_wino4(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
-                        const float* R, float* Y, int COUT, int relu, hipStream_t st) {
+                        const float* R, float* Y, int COUT, int relu, int rows, hipStream_t st) {
   using G = Wino4Geom;
-  const int cgroups = cdiv(W, G::TW), trows = cdiv(H, G::TH);
+  const int cgroups = cdiv(W, G::TW), trows = cdiv(rows, G::TH);   // (rows < H: the tile rows that cover them only)
   const size_t lds = (size_t)G::LDS_BYTES + 16;
   auto kernel = k_conv3x3_wino4<HAS_R>;
   constexpr int MAXDEV = 16;
@@ -728,19 +728,31 @@ int pa_wino4_read_stamps(unsigned long long* host) {
 // conv3x3, stride 1, pad 1, via Winograd F(4x4,3x3): Y = [relu](conv(X) + shift [+ R]).  X, R, Y: NHWC float32.
 // U: G g G^T (BatchNorm scale folded) in the slab layout of weights.winograd4_pack / pa_winograd4_pack_host:
 // [cout/32][cin/8][row = 32 xi + n][8], xi = 6a + b.
+int pa_conv3x3_wino4_rows(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                          const float* R, float* Y, int cout, int relu, int rows, void* stream);
+
 int pa_conv3x3_wino4(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
                      const float* R, float* Y, int cout, int relu, void* stream) {
-  if (B <= 0) return 0;
+  return pa_conv3x3_wino4_rows(X, B, H, W, cin, U, shift, R, Y, cout, relu, H, stream);
+}
+
+// the same convolution for the output rows 0 .. rows - 1 only (rows == H, or a multiple of 4 below it: the rest of
+// the map is somebody else's -- pa_emb_forward gives the last two rows of a map whose height is 2 (mod 4) to the
+// F(2x2) kernel instead of padding them to a tile row that is half empty: 10-row maps, 12 -> 10 rows of work)
+int pa_conv3x3_wino4_rows(const float* X, int B, int H, int W, int cin, const float* U, const float* shift,
+                          const float* R, float* Y, int cout, int relu, int rows, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  PA_REQUIRE(rows == H || (rows < H && rows % 4 == 0), "pa_conv3x3_wino4_rows: rows must be H or a multiple of 4 below it");
   PA_REQUIRE(cin % 8 == 0 && cin >= 32 && cout % pa::W_BN == 0,
              "pa_conv3x3_wino4: cin %% 8 == 0, cin >= 32 and cout %% 32 == 0 required");
   PA_REQUIRE((long)H * W * (cin > cout ? cin : cout) * 4 < (1L << 28),
              "pa_conv3x3_wino4: one image must be smaller than 256 MB");
   // `flops` = the direct convolution's (the reference's operation); the kernel executes 36/144 of them
-  pa::ProfScope prof("k_conv3x3_wino4", stream, 2.0 * 9 * cin * cout * (double)B * H * W,
-                     4.0 * ((double)B * H * W * cin + (double)B * H * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
+  pa::ProfScope prof("k_conv3x3_wino4", stream, 2.0 * 9 * cin * cout * (double)B * rows * W,
+                     4.0 * ((double)B * rows * W * cin + (double)B * rows * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
-  const int rc = R != nullptr ? pa::launch_wino4<true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st)
-                              : pa::launch_wino4<false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, st);
+  const int rc = R != nullptr ? pa::launch_wino4<true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
+                              : pa::launch_wino4<false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
   if (rc != 0) return rc;
   PA_CHECK_LAUNCH("pa_conv3x3_wino4");
   return 0;

@@ -95,7 +95,7 @@ __device__ __forceinline__ void wino_patch_bases(int (&pbase)[8], int t, int g, 
 // the index space is padded to a multiple of 8 (pixel tile, image) pairs: padding tiles are computed on
 // the last real tile's data and not stored (valid = 0).
 __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw, int n_tiles, int th,
-                                                int tw, int num_pb) {
+                                                int tw, int num_pb, int y_first = 0) {
   WinoTile o;
   const int xcd = q & 7, r = q >> 3;
   int pb = (r / n_tiles) * 8 + xcd;
@@ -104,7 +104,7 @@ __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw
   pb = pb < num_pb ? pb : num_pb - 1;
   const int pix = pb % tiles_hw;
   o.b = pb / tiles_hw;
-  o.y0 = (pix / tiles_w) * th;
+  o.y0 = (pix / tiles_w) * th + y_first;   // (y_first: the launch covers the rows from there on, pa_conv3x3_wino_rows)
   o.x0 = (pix % tiles_w) * tw;
   return o;
 }

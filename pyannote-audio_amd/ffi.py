@@ -184,6 +184,10 @@ _OPTIONAL: list[tuple] = [
                          c_fp], C.c_int),
     ("pa_conv3x3_wino4", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
                           c_fp], C.c_int),
+    ("pa_conv3x3_wino4_rows", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
+                               C.c_int, c_fp], C.c_int),
+    ("pa_conv3x3_wino_rows", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
+                              C.c_int, c_fp], C.c_int),
     ("pa_pdist_f64", [c_fp, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_cdist_cosine_f64", [c_fp, C.c_int, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp], C.c_int),
     ("pa_centroid_means", [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_fp, c_fp], C.c_int),

@@ -229,6 +229,43 @@ def test_conv3x3_winograd_f4(gpu_device):
         assert elementwise <= 8.0, (cin, cout, H, W, B, elementwise)
 
 
+def test_conv3x3_row_split_between_f4_and_f2(gpu_device):
+    """a map whose height is 2 (mod 4) -- layer 4 on 10 s chunks: 10 x 125 x 256 -- is split by pa_emb_forward: rows
+    0 .. H - 3 through pa_conv3x3_wino4_rows, the last two through pa_conv3x3_wino_rows; together they are the whole
+    convolution (every output pixel written exactly once: Y starts as NaN), with and without the residual, for
+    heights 10, 6 and 18 and a ragged width."""
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.weights import winograd4_pack, winograd4_weights, winograd_pack, winograd_weights
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(41)
+    for cin, cout, H, W, B, use_res in [(256, 256, 10, 125, 5, True), (128, 128, 6, 70, 3, False),
+                                        (64, 64, 18, 129, 2, True), (256, 256, 10, 125, 40, False)]:
+        x = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+        sh = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, W, generator=g)
+        ref = F.conv2d(x, wt, stride=1, padding=1) + sh.view(1, -1, 1, 1)
+        ref = F.relu(ref + res if use_res else ref)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        v = winograd4_pack(winograd4_weights(wt)).to(gpu_device)
+        u = winograd_pack(winograd_weights(wt)).to(gpu_device)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device) if use_res else None
+        shd = sh.to(gpu_device)
+        y = torch.full((B, H, W, cout), float("nan"), device=gpu_device)
+        ffi.check(lib.pa_conv3x3_wino4_rows(ffi.ptr(xd), B, H, W, cin, ffi.ptr(v), ffi.ptr(shd), ffi.ptr(rd),
+                                            ffi.ptr(y), cout, 1, H - 2, ffi.stream()), "wino4_rows")
+        torch.cuda.synchronize()
+        assert torch.isnan(y[:, H - 2:]).all() and not torch.isnan(y[:, :H - 2]).any()
+        ffi.check(lib.pa_conv3x3_wino_rows(ffi.ptr(xd), B, H, W, cin, ffi.ptr(u), ffi.ptr(shd), ffi.ptr(rd),
+                                           ffi.ptr(y), cout, 1, H - 2, ffi.stream()), "wino_rows")
+        torch.cuda.synchronize()
+        got = y.permute(0, 3, 1, 2).cpu()
+        assert not torch.isnan(got).any()
+        top = (got[:, :, :H - 2] - ref[:, :, :H - 2]).abs().max().item() / ref.abs().max().item()
+        assert top <= 1e-4, (cin, H, W, top)                                     # F(4x4) rows: its per-convolution bound
+        assert north_star_ratio(f"row_split_f2_rows_{cin}_{H}x{W}", got[:, :, H - 2:], ref[:, :, H - 2:]) <= 1.0
+
+
 def test_shortcut_gemm_reads_strided_pixels_in_place(gpu_device):
     """pa_gemm_tn_s2 (the 1x1 stride-2 shortcut convolution + folded BatchNorm of the first block of layers 2-4,
     resnet.py:109-118) directly through the C ABI vs F.conv2d(kernel 1, stride 2): even and ODD maps (Ho = ceil(H/2):
