@@ -166,15 +166,31 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
   struct Tile {
     int b, n0, y0, x0;
   };
+  // XCD-aware tile order (as wino_decode, emb_winograd_geom.h): tile t runs on XCD t % 8 (tile_queue.h) and the
+  // n_tiles workgroups that read the same input patch -- same image, same pixel tile, different cout slices -- are
+  // consecutive claims of ONE XCD: the patch comes from HBM once and from that XCD's L2 n_tiles - 1 times.  (Until
+  // round 5 the cout slice was the SLOWEST index: the slices of a patch ran a whole image stack apart and every one
+  // fetched it from HBM -- 2.07x the algorithmic bytes, profiles/r4_traffic.json.)  (pixel tile, image) pair
+  // pb = (r / n_tiles) * 8 + xcd; the index space is padded to whole XCD stripes, pairs >= num_pb are holes.
+  const int num_pb = total_tiles / n_tiles;
+  auto pair_of = [&](int t) { return ((t >> 3) / n_tiles) * 8 + (t & 7); };
   auto decode = [&](int t) {
     Tile q;
-    const int pix = t % tiles_hw;
-    const int rest = t / tiles_hw;
-    q.n0 = (rest % n_tiles) * BN;
-    q.b = rest / n_tiles;
+    const int pb = pair_of(t);
+    q.n0 = (((t >> 3) % n_tiles)) * BN;
+    const int pix = pb % tiles_hw;
+    q.b = pb / tiles_hw;
     q.y0 = (pix / tiles_w) * TH;
     q.x0 = (pix % tiles_w) * G::TW;
     return q;
+  };
+  // a claim's raw counter value -> a real tile (holes are skipped by claiming again), or -1
+  auto resolve = [&](const TileQueue& tqq, int r) {
+    for (;;) {
+      const int t = tq_resolve(tqq, r);
+      if (t < 0 || pair_of(t) < num_pb) return t;
+      r = tq_claim_own(tqq);
+    }
   };
   u32x4 rp[NP], rw[NW];
   // Per-lane byte offsets of a tile's staging loads (halo / out-of-image / padding lanes out of bounds: the hardware
@@ -243,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
   // tile k starts and publishes it through LDS during tile k's first stage, in time for the prefetch of
   // its first channel block in tile k's last stage
   __shared__ int s_next;
-  const TileQueue tq{counters, (int)(blockIdx.x & 7), (total_tiles + 7) >> 3};
-  if (tid == 0) s_next = tq_resolve_upto(tq, tq_claim_own(tq), total_tiles);
+  const TileQueue tq{counters, (int)(blockIdx.x & 7), ((num_pb + 7) >> 3) * n_tiles};
+  if (tid == 0) s_next = resolve(tq, tq_claim_own(tq));
   __syncthreads();
   int t = s_next;
   if (t < 0) {
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
     for (int c0 = 0; c0 < CIN; c0 += CB) {
       __syncthreads();  // every wave is done reading the previous stage from LDS
       lstore();
-      if (c0 == 0 && tid == 0) s_next = tq_resolve_upto(tq, ahead, total_tiles);
+      if (c0 == 0 && tid == 0) s_next = resolve(tq, ahead);
       __syncthreads();
       if (c0 == 0) {     // CIN >= 2 channel blocks: the next tile is known before the last stage
         tn = s_next;
