@@ -194,19 +194,20 @@ __device__ unsigned long long g_w4_stamps[8 * 4 * 64 * 10];
 
 constexpr int W4_AGPR_POINTS = 32;   // 256 AccVGPRs; 4 points (32 registers) stay architectural
 
-constexpr int W4_PIECES = Wino4Geom::PINSTR + 9;   // 13 of the wave's patch + its 9 of the 36 U pieces
-struct Wino4Lanes {       // per-lane patch offsets + class bits (wino4_patch_lanes), one per patch piece
-  int a[Wino4Geom::PINSTR];
+// pieces of a stage per wave: PIN of the wave's patch (13 row-shaped / 18 tile-linear units) + its 9 of the 36 U pieces
+template <int PIN>
+struct Wino4Lanes {       // per-lane patch offsets (+ class bits, wino4_patch_lanes), one per patch piece
+  int a[PIN];
 };
 // (I is a compile-time constant at every call site after unrolling)
-__device__ __forceinline__ void wino4_piece(const int I, const Wino4Stage& st, const Wino4Lanes& pl, int lane,
+template <int PIN>
+__device__ __forceinline__ void wino4_piece(const int I, const Wino4Stage& st, const Wino4Lanes<PIN>& pl, int lane,
                                             int slw) {
-  using G = Wino4Geom;
-  if (I < G::PINSTR) {
-    const int off = pl.a[I < G::PINSTR ? I : 0] & st.keep;
+  if (I < PIN) {
+    const int off = pl.a[I < PIN ? I : 0] & st.keep;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.xsrd, (lds4_ptr_t)(st.pbuf + 1024 * I), 16, off, 0, 0, 0);
   } else {
-    const int k = slw + 4 * (I - G::PINSTR);
+    const int k = slw + 4 * (I - PIN);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.usrd, (lds4_ptr_t)(st.ubuf + 1024 * k), 16, lane * 16,
                                              st.usoff + 1024 * k, 0, 0);
   }
@@ -225,11 +226,10 @@ struct Wino4Dma {           // wave-uniform LDS byte addresses
 __device__ __forceinline__ unsigned w4_lds_addr(const void* p) {
   return (unsigned)(size_t)(lds4_ptr_t)const_cast<void*>(p);
 }
-template <int I>
-__device__ __forceinline__ void wino4_piece_asm(const Wino4Stage& st, const Wino4Dma& d, const int (&plm)[13],
+template <int I, int PIN>
+__device__ __forceinline__ void wino4_piece_asm(const Wino4Stage& st, const Wino4Dma& d, const int (&plm)[PIN],
                                                 int lane16) {
-  using G = Wino4Geom;
-  if constexpr (I < G::PINSTR) {
+  if constexpr (I < PIN) {
     asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds"
                  :: "s"(d.patch_lds), "i"(1024 * I), "v"(plm[I]), "s"(st.xsrd)
                  : "memory");
@@ -237,34 +237,71 @@ __device__ __forceinline__ void wino4_piece_asm(const Wino4Stage& st, const Wino
     int tmp;
     asm volatile("s_add_u32 m0, %1, %2\n\ts_add_u32 %0, %3, %2\n\tbuffer_load_dwordx4 %4, %5, %0 offen lds"
                  : "=&s"(tmp)
-                 : "s"(d.u_lds), "i"(4096 * (I - G::PINSTR)), "s"(d.usoff), "v"(lane16), "s"(st.usrd)
+                 : "s"(d.u_lds), "i"(4096 * (I - PIN)), "s"(d.usoff), "v"(lane16), "s"(st.usrd)
                  : "memory");
   }
 }
 // (the piece number is a constant after unrolling: the switch folds)
+template <int PIN>
 __device__ __forceinline__ void wino4_piece_asm_n(const int piece, const Wino4Stage& st, const Wino4Dma& d,
-                                                  const int (&plm)[13], int lane16) {
+                                                  const int (&plm)[PIN], int lane16) {
   switch (piece) {
-#define W4_CASE(I) case I: wino4_piece_asm<I>(st, d, plm, lane16); break;
+#define W4_CASE(I) case I: if constexpr (I < PIN + 9) wino4_piece_asm<I, PIN>(st, d, plm, lane16); break;
     W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(9)
     W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(15) W4_CASE(16) W4_CASE(17) W4_CASE(18)
-    W4_CASE(19) W4_CASE(20) W4_CASE(21)
+    W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(24) W4_CASE(25) W4_CASE(26)
 #undef W4_CASE
     default: break;
   }
 }
-__device__ __forceinline__ void wino4_issue_all(const Wino4Stage& st, const Wino4Lanes& pl, int lane, int slw) {
+template <int PIN>
+__device__ __forceinline__ void wino4_issue_all(const Wino4Stage& st, const Wino4Lanes<PIN>& pl, int lane, int slw) {
 #pragma unroll
-  for (int i = 0; i < W4_PIECES; ++i) wino4_piece(i, st, pl, lane, slw);
+  for (int i = 0; i < PIN + 9; ++i) wino4_piece<PIN>(i, st, pl, lane, slw);
 }
 
-template <bool HAS_R>
+// ---- tile-linear units (emb_winograd4_geom.h): what a lane needs of its unit
+struct Wino4LinUnit {
+  int b0;               // wave-uniform: first image of the unit
+  Wino4LinTile tc;      // the tile this lane transforms and stores (t = lane & 15)
+};
+// per-lane DMA offsets of unit u (18 pieces) + the lane's compute tile
+__device__ __forceinline__ Wino4LinUnit wino4_lin_unit(int u, int tcols, int trows, int total_tiles, int H, int W,
+                                                       int CIN, int lane, int (&off)[Wino4LinGeom::PINSTR]) {
+  Wino4LinUnit o;
+  o.b0 = __builtin_amdgcn_readfirstlane(wino4_lin_b0(u, tcols, trows, total_tiles));
+  o.tc = wino4_lin_tile(16 * u + (lane & 15), tcols, trows, total_tiles, o.b0);
+  const Wino4LinTile td = wino4_lin_tile(16 * u + ((lane >> 1) & 15), tcols, trows, total_tiles, o.b0);
+#pragma unroll
+  for (int i = 0; i < Wino4LinGeom::PINSTR; ++i) off[i] = wino4_lin_patch_lane(i, td, H, W, CIN, lane);
+  return o;
+}
+// staging context of a tile-linear unit: the descriptor starts at the unit's first image and runs to the end of the
+// tensor (clamped to 2^31 - 1); every halo is an out-of-bounds lane offset, `keep` passes everything through
+__device__ __forceinline__ Wino4Ctx wino4_lin_ctx(const float* __restrict__ X, int H, int W, int CIN, int nimg, int b0,
+                                                  int n0) {
+  using G = Wino4LinGeom;
+  const long img = (long)H * W * CIN;
+  const long long rest = (long long)(nimg - b0) * img * 4;
+  Wino4Ctx c;
+  c.xp = X + (long)b0 * img;
+  c.xnum = (int)(rest > 0x7fffffffLL ? 0x7fffffffLL : rest);
+  c.keep = -1;
+  c.usoff = (n0 / W_BN) * (CIN / G::CB) * G::USLAB_BYTES;
+  return c;
+}
+
+// LIN: tile-linear units (16 consecutive tiles of the raster order; `cgroups` = tile columns, `num_units` = total
+// tiles, `nimg` = images) instead of row-shaped ones -- see emb_winograd4_geom.h and launch_wino4.
+template <bool HAS_R, bool LIN>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT, int relu,
-    int cgroups, int trows, int num_units, int num_groups, int n_tiles, int total_work,
+    int cgroups, int trows, int num_units, int num_groups, int n_tiles, int total_work, int nimg,
     int* __restrict__ counters) {
-  using G = Wino4Geom;
+  using G = std::conditional_t<LIN, Wino4LinGeom, Wino4Geom>;
+  constexpr int PIN = G::PINSTR;
+  constexpr int W4_PIECES = PIN + 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int t = lane & 15, g = lane >> 4;
@@ -281,10 +318,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     if (tid == 0) tq_done(tq, gridDim.x);
     return;
   }
-  const int x0_last = (cgroups - 1) * G::TW;
-  Wino4Lanes pl;
-  wino4_patch_lanes(pl.a, W, CIN, lane, x0_last);
-  const int pbase0 = wino4_patch_base(t, g, 0), pbase1 = wino4_patch_base(t, g, 1);
+  const int x0_last = LIN ? 0 : (cgroups - 1) * Wino4Geom::TW;
+  Wino4Lanes<PIN> pl;      // row-shaped units: per kernel; tile-linear: the CURRENT unit's lane offsets
+  Wino4Lanes<PIN> npl;     // tile-linear: the next unit's (computed in the current tile's last stage)
+  if constexpr (!LIN) wino4_patch_lanes(pl.a, W, CIN, lane, x0_last);
+  const int pbase0 = LIN ? wino4_lin_patch_base(t, g) : wino4_patch_base(t, g, 0);
+  const int pbase1 = LIN ? pbase0 : wino4_patch_base(t, g, 1);
   const int ubase = wino4_u_base(t, g);
   const int lane16 = lane * 16;
   W4Const kc;
@@ -299,12 +338,24 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   // this wave's unit of the claimed group (a group past the end / a unit past the last one is computed on the last
   // real unit's data and not stored: valid = 0)
   Wino4Work wk = wino4_decode(q, n_tiles, num_groups);
-  Wino4Unit cur = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units), nxt = cur;
-  cur.valid &= wk.valid;
+  Wino4Unit cur = Wino4Unit{0, 0, 0, 0}, nxt = cur;
+  Wino4LinUnit lcur = Wino4LinUnit{0, Wino4LinTile{0, 0, 0, 0}}, lnxt = lcur;
   int cur_n0 = wk.n0, nxt_n0 = wk.n0;
-  Wino4Ctx cctx = wino4_ctx(X, H, W, CIN, cur, cur_n0, x0_last), nctx = cctx;
+  Wino4Ctx cctx;
+  if constexpr (LIN) {
+    lcur = wino4_lin_unit(wk.unit0 + slw, cgroups, trows, num_units, H, W, CIN, lane, pl.a);
+    lcur.tc.valid &= wk.valid;
+    cctx = wino4_lin_ctx(X, H, W, CIN, nimg, lcur.b0, cur_n0);
+  } else {
+    cur = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
+    cur.valid &= wk.valid;
+    cctx = wino4_ctx(X, H, W, CIN, cur, cur_n0, x0_last);
+  }
+  nxt = cur;
+  lnxt = lcur;
+  Wino4Ctx nctx = cctx;
   int buf = 0;
-  wino4_issue_all(wino4_stage(cctx, U, COUT, CIN, 0, my_patch, ubufs), pl, lane, slw);
+  wino4_issue_all<PIN>(wino4_stage(cctx, U, COUT, CIN, 0, my_patch, ubufs), pl, lane, slw);
   int claim = 0;
   if (tid == 0) claim = tq_claim_own(tq);
   int nq = -1;
@@ -331,7 +382,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if !defined(PA_W4_NOPATCHREAD) && !defined(PA_W4_NOTRANSFORM)
 #pragma unroll
-      for (int i = 0; i < 6; ++i) x_first[i] = w4_lds_read64(my_patch + pbase0 + wino4_patch_k(i, 0));
+      for (int i = 0; i < 6; ++i)
+        x_first[i] = w4_lds_read64(my_patch + pbase0 + (LIN ? wino4_lin_patch_k(i, 0) : wino4_patch_k(i, 0)));
 #endif
       __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done with the other buffer
       asm volatile("" ::: "memory");
@@ -348,10 +400,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         nq = mail[0];   // (written by thread 0 in front of this stage's barrier)
         stage_next = nq >= 0;
         wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups);
-        nxt = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
-        nxt.valid &= wk.valid;
         nxt_n0 = wk.n0;
-        nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
+        if constexpr (LIN) {
+          // (the next unit's 18 lane offsets are computed behind the transform, where the registers are free)
+          lnxt.b0 = __builtin_amdgcn_readfirstlane(wino4_lin_b0(wk.unit0 + slw, cgroups, trows, num_units));
+          nctx = wino4_lin_ctx(X, H, W, CIN, nimg, lnxt.b0, nxt_n0);
+        } else {
+          nxt = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
+          nxt.valid &= wk.valid;
+          nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
+        }
         nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
 
       }
@@ -376,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #ifdef PA_W4_NOPATCHREAD   // development A/B (timing only): the arithmetic on register values, no LDS reads
 #define W4_RD(i, j) f32x2{(float)(lane + (i)), (float)(s + (j))}
 #else
-#define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + wino4_patch_k(i, j))
+#define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + (LIN ? wino4_lin_patch_k(i, j) : wino4_patch_k(i, j)))
 #endif
 #pragma unroll
 #ifdef PA_W4_NOPATCHREAD
@@ -422,9 +480,22 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // assembly because the accumulators must be PINNED: 32 points in the 256 AccVGPRs, 4 in architectural
       // registers (left to the register allocator, 288 accumulators + the transform spill ~200 registers).
 #if PA_W4_ASM_DMA
-      int plm[G::PINSTR];
+      int plm[PIN];
+      if constexpr (LIN) {
+        if (s + 1 < nstages) {
 #pragma unroll
-      for (int i = 0; i < G::PINSTR; ++i) plm[i] = pl.a[i] & nst.keep;
+          for (int i = 0; i < PIN; ++i) plm[i] = pl.a[i];
+        } else {
+          // the next unit: its lane offsets (and this lane's tile of it)
+          lnxt = wino4_lin_unit(wk.unit0 + slw, cgroups, trows, num_units, H, W, CIN, lane, npl.a);
+          lnxt.tc.valid &= wk.valid;
+#pragma unroll
+          for (int i = 0; i < PIN; ++i) plm[i] = npl.a[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PIN; ++i) plm[i] = pl.a[i] & nst.keep;
+      }
       const Wino4Dma dma{w4_lds_addr(my_patch), w4_lds_addr(uother) + 1024u * slw, nst.usoff + 1024 * slw};
 #endif
       auto mfma_run = [&](auto first_stage) {
@@ -482,9 +553,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
             if ((m == 4 || m == 6) && stage_next) {       // wave-uniform; pieces xp, xp + 1 of the next stage
               const int piece = xp + ((m - 4) >> 1);
 #if PA_W4_ASM_DMA
-              if (piece < W4_PIECES) wino4_piece_asm_n(piece, nst, dma, plm, lane16);
+              if (piece < W4_PIECES) wino4_piece_asm_n<PIN>(piece, nst, dma, plm, lane16);
 #else
-              if (piece < W4_PIECES) wino4_piece(piece, nst, pl, lane, slw);
+              if (piece < W4_PIECES) wino4_piece<PIN>(piece, nst, pl, lane, slw);
 #endif
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -512,17 +583,31 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         k4.p4 = f32x4{p4, p4, p4, p4}; k4.p8 = f32x4{p8, p8, p8, p8};
         k4.m2 = f32x4{m2, m2, m2, m2}; k4.m8 = f32x4{m8, m8, m8, m8};
       }
-      const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(
-          Y + (long)cur.b * H * W * COUT, 0, H * W * COUT * 4, 0x00020000);
+      // row-shaped unit: one image, rows past its end fall out of the descriptor by themselves.  Tile-linear unit: the
+      // descriptor runs from the unit's first image to the end of the tensor and every lane knows how many output
+      // rows of ITS tile exist (`rows_ok`; the rows below belong to the next image).
+      const long oimg = (long)H * W * COUT;
+      const int ob = LIN ? lcur.b0 : cur.b;
+      const long long orest = (long long)(LIN ? nimg - ob : 1) * oimg * 4;
+      const int onum = (int)(orest > 0x7fffffffLL ? 0x7fffffffLL : orest);
+      const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc(Y + (long)ob * oimg, 0, onum, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsrd = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(HAS_R ? R + (long)cur.b * H * W * COUT : Y), 0, H * W * COUT * 4, 0x00020000);
+          const_cast<float*>(HAS_R ? R + (long)ob * oimg : Y), 0, onum, 0x00020000);
       constexpr int OOB = (int)0x80000000;
-      const int xl = cur.x0 + 4 * t;
-      const int obase = ((cur.y0 * W + xl) * COUT + cur_n0 + 4 * g) * 4;
+      const int xl = LIN ? lcur.tc.x : cur.x0 + 4 * t;
+      const int yl = LIN ? lcur.tc.b * H + lcur.tc.y : cur.y0;
+      const int rows_ok = LIN ? H - lcur.tc.y : 4;
+      const int tile_ok = LIN ? lcur.tc.valid : cur.valid;
+      const int obase = ((yl * W + xl) * COUT + cur_n0 + 4 * g) * 4;
       const int srow = W * COUT * 4, spix = COUT * 4;
       int offq[4];
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) offq[qq] = (cur.valid && xl + qq < W) ? obase + qq * spix : OOB;
+      for (int qq = 0; qq < 4; ++qq) offq[qq] = (tile_ok && xl + qq < W) ? obase + qq * spix : OOB;
+      // byte offset of output (row p, column qq) of this lane's tile, channel group cg -- or out of bounds
+      auto ooff = [&](const int p, const int qq, const int cg) {
+        if constexpr (LIN) return (offq[qq] == OOB || p >= rows_ok) ? OOB : offq[qq] + p * srow + 64 * cg;
+        else return offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg;
+      };
       const float lo = relu ? 0.f : -__builtin_inff();
       const f32x4 lo4 = {lo, lo, lo, lo};
       // Every accumulator is read ONCE, column by column of the 6x6 point grid: y = A^T M[:, b] (10 operations),
@@ -541,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       f32x4 held[4][4];
       auto store_held = [&](const int k) {   // (k: compile-time after unrolling)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, held[k >> 2][k & 3]), ysrd,
-                                               offq[k & 3] == OOB ? OOB : offq[k & 3] + (k >> 2) * srow, 0, 0);
+                                               ooff(k >> 2, k & 3, 0), 0, 0);
       };
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
@@ -564,8 +649,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
               rv[p][qq] = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                             rsrd, offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0));
+                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, ooff(p, qq, cg), 0, 0));
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 o[4][4];
@@ -625,8 +709,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
               for (int qq = 0; qq < 4; ++qq)
                 rv[p][qq] = __builtin_bit_cast(
-                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                               rsrd, offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0));
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, ooff(p, qq, cg), 0, 0));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -656,8 +739,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd,
-                                                     offq[qq] == OOB ? OOB : offq[qq] + p * srow + 64 * cg, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd, ooff(p, qq, cg), 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #if PA_W4_STAMP
@@ -670,6 +752,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     W4_STAMP_FLUSH();
     if (nq < 0) break;
     cur = nxt;
+    if constexpr (LIN) {
+      lcur = lnxt;
+      pl = npl;
+    }
     cur_n0 = nxt_n0;
     cctx = nctx;
     if (tid == 0) claim = tq_claim_own(tq);
@@ -677,13 +763,27 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   if (tid == 0) tq_done(tq, gridDim.x);
 }
 
-template <bool HAS_R>
+// row-shaped units pad every tile row to whole groups of 16 tiles, tile-linear units only the end of the launch, but
+// stage 18 instead of 13 patch pieces per stage (+ ~3.5 % per stage, profiles/r5_wino4_linear_units.txt): linear when
+// that saves more than it costs.  PA_WINO4_LINEAR=0 / 1 forces one of them (A/B aid).
+static bool wino4_linear_wanted(int B, int H, int W, int rows) {
+  if (rows != H) return false;                      // (row ranges: the row-shaped kernel)
+  static const char* e = getenv("PA_WINO4_LINEAR");
+  if (e != nullptr) return atoi(e) != 0;
+  const long tcols = cdiv(W, 4), trows = cdiv(H, 4);
+  const long lin_units = cdiv((long)B * trows * tcols, 16), row_units = (long)B * trows * cdiv(W, 64);
+  return lin_units * 106 <= row_units * 100;
+}
+
+template <bool HAS_R, bool LIN>
 static int launch_wino4(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                         const float* R, float* Y, int COUT, int relu, int rows, hipStream_t st) {
-  using G = Wino4Geom;
-  const int cgroups = cdiv(W, G::TW), trows = cdiv(rows, G::TH);   // (rows < H: the tile rows that cover them only)
+  using G = std::conditional_t<LIN, Wino4LinGeom, Wino4Geom>;
+  // row-shaped: column groups of 64 pixels x tile rows (rows < H: the tile rows that cover them only);
+  // tile-linear: tile columns x tile rows, units of 16 consecutive tiles
+  const int cgroups = LIN ? cdiv(W, 4) : cdiv(W, Wino4Geom::TW), trows = cdiv(rows, 4);
   const size_t lds = (size_t)G::LDS_BYTES + 16;
-  auto kernel = k_conv3x3_wino4<HAS_R>;
+  auto kernel = k_conv3x3_wino4<HAS_R, LIN>;
   constexpr int MAXDEV = 16;
   static int cus_of[MAXDEV] = {0};
   int dev = 0;
@@ -696,7 +796,8 @@ static int launch_wino4(const float* X, int B, int H, int W, int CIN, const floa
     cus_of[dev] = cus;
   }
   const int n_tiles = COUT / W_BN;
-  const long num_units = (long)cgroups * trows * B;
+  const long total_tiles = (long)cgroups * trows * B;                       // (LIN)
+  const long num_units = LIN ? (total_tiles + 15) / 16 : (long)cgroups * trows * B;
   const long num_groups = (num_units + 3) / 4;
   const long total = ((num_groups + 7) / 8) * 8 * n_tiles;   // padded to whole XCD stripes
   const int resident = cus_of[dev] & ~7;                      // one workgroup per CU
@@ -706,8 +807,9 @@ static int launch_wino4(const float* X, int B, int H, int W, int CIN, const floa
     set_error("pa_conv3x3_wino4: cannot allocate the tile counters");
     return 2;
   }
+  // (tile-linear: the kernel's `num_units` argument carries the number of TILES)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, cgroups, trows,
-                     (int)num_units, (int)num_groups, n_tiles, (int)total, counters);
+                     (int)(LIN ? total_tiles : num_units), (int)num_groups, n_tiles, (int)total, B, counters);
   return 0;
 }
 
@@ -751,8 +853,18 @@ int pa_conv3x3_wino4_rows(const float* X, int B, int H, int W, int cin, const fl
   pa::ProfScope prof("k_conv3x3_wino4", stream, 2.0 * 9 * cin * cout * (double)B * rows * W,
                      4.0 * ((double)B * rows * W * cin + (double)B * rows * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
-  const int rc = R != nullptr ? pa::launch_wino4<true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
-                              : pa::launch_wino4<false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
+  int rc;
+  if (pa::wino4_linear_wanted(B, H, W, rows)) {
+    // a unit may straddle images: its lane offsets count from the unit's first image
+    const long per = (long)pa::cdiv(H, 4) * pa::cdiv(W, 4);
+    const long span = (15 / per + 2) * (long)H * W * (cin > cout ? cin : cout) * 4;
+    PA_REQUIRE(span < (1L << 31), "pa_conv3x3_wino4: the images a 16-tile unit can touch must stay below 2 GB");
+    rc = R != nullptr ? pa::launch_wino4<true, true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
+                      : pa::launch_wino4<false, true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
+  } else {
+    rc = R != nullptr ? pa::launch_wino4<true, false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
+                      : pa::launch_wino4<false, false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
+  }
   if (rc != 0) return rc;
   PA_CHECK_LAUNCH("pa_conv3x3_wino4");
   return 0;

@@ -115,4 +115,61 @@ __device__ __forceinline__ Wino4Unit wino4_unit(int u, int cgroups, int trows, i
   return o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TILE-LINEAR units (round 5): a wave's unit = 16 CONSECUTIVE tiles of the raster order (image, tile row, tile
+// column) -- it may straddle tile rows and images.  The row-shaped unit above pads every tile row to whole groups of 16
+// tiles: fine for the maps of 10 s chunks (125 / 63 / 32 tiles per row), ruinous for the narrow maps of short chunks
+// (3 s: 38 / 19 / 10 tiles per row -> 1.26x / 1.68x / 1.60x the useful tiles).  Linear units pad once per launch.
+// The tiles of a unit no longer share their halo, so each tile's 6 x 6 patch is staged on its own:
+//   patch  (private to the wave) 36 elements x 16 tiles, one (element, tile) = one 32-B LDS row: row = 16 e + t,
+//          e = 6 i + j; lane (t, g) of the transform reads row 16 e + t -- consecutive lanes, consecutive rows, with
+//          the same quad swizzle on bit 3 of t.  576 rows = 18 DMA pieces per stage (13 for the row-shaped unit).
+//   Every halo pixel outside the image is zero-filled through an out-of-bounds LANE offset (there are no class bits:
+//   the neighbours in memory are real pixels of the next row / image).
+struct Wino4LinGeom {
+  static constexpr int CB = 8;
+  static constexpr int PROWS = 36 * 16;              // 576 LDS rows of 32 B
+  static constexpr int PINSTR = PROWS / 32;          // 18 DMA pieces of 1 KB per wave and stage
+  static constexpr int PATCH_BYTES = PINSTR * 1024;  // 18 432 per wave
+  static constexpr int USLAB_BYTES = Wino4Geom::USLAB_BYTES;
+  static constexpr int LDS_BYTES = 4 * PATCH_BYTES + 2 * USLAB_BYTES;   // 147 456
+};
+struct Wino4LinTile {   // per LANE
+  int b;      // image, relative to the first image of the unit
+  int y, x;   // top-left output pixel
+  int valid;
+};
+// tile T of the raster order; tiles past the end repeat the last real one (computed, never stored)
+__device__ __forceinline__ Wino4LinTile wino4_lin_tile(int T, int tcols, int trows, int total_tiles, int b0) {
+  Wino4LinTile o;
+  o.valid = T < total_tiles;
+  const int TT = T < total_tiles ? T : total_tiles - 1;
+  const int per = tcols * trows, b = TT / per, r = TT - b * per;
+  const int ty = r / tcols;
+  o.b = b - b0;
+  o.y = 4 * ty;
+  o.x = 4 * (r - ty * tcols);
+  return o;
+}
+// first image of unit u (wave-uniform): the image of its first tile
+__device__ __forceinline__ int wino4_lin_b0(int u, int tcols, int trows, int total_tiles) {
+  const int T = 16 * u < total_tiles ? 16 * u : total_tiles - 1;
+  return T / (tcols * trows);
+}
+// DMA: piece i fills LDS rows 32 i .. 32 i + 31; lane l -> row 32 i + (l >> 1) = element e = 2 i + (l >> 5) of tile
+// td = (l >> 1) & 15, 16-byte half l & 1, which holds channel quad (l & 1) ^ swz(td).  -> byte offset from the first
+// pixel of the unit's first image (stage 0), or the out-of-bounds marker.  `td_tile` = wino4_lin_tile(16 u + td, ...).
+__device__ __forceinline__ int wino4_lin_patch_lane(int piece, const Wino4LinTile& td_tile, int H, int W, int CIN,
+                                                    int lane) {
+  const int e = 2 * piece + (lane >> 5), i = e / 6, j = e - 6 * i;
+  const int iy = td_tile.y - 1 + i, ix = td_tile.x - 1 + j;
+  const int td = (lane >> 1) & 15;
+  const int quad = (lane & 1) ^ wino4_swz(td);
+  const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+  return in ? (((td_tile.b * H + iy) * W + ix) * CIN + 4 * quad) * 4 : WCLS_PAD;
+}
+// transform reads: lane (t, g), element (i, j): base(t, g) + K_ij
+__device__ __forceinline__ int wino4_lin_patch_base(int t, int g) { return 32 * t + 8 * (g ^ (2 * wino4_swz(t))); }
+constexpr int wino4_lin_patch_k(int i, int j) { return 512 * (6 * i + j); }
+
 }  // namespace pa

@@ -139,7 +139,94 @@ static int check_order(int B, int H, int W, int n_tiles) {
   return 0;
 }
 
+// ---- tile-linear units (Wino4LinGeom): DMA and transform reads of unit u of a (B, H, W) stack of maps, stage c0
+struct LinCell {
+  int kind;      // 0 = never written, 1 = zero fill, 2 = data
+  int b;         // image
+  long gpix;     // iy * W + ix
+  int quad;
+};
+static int check_lin_unit(int B, int H, int W, int CIN, int u, int c0) {
+  using G = Wino4LinGeom;
+  const int tcols = (W + 3) / 4, trows = (H + 3) / 4, total = B * trows * tcols;
+  const int b0 = wino4_lin_b0(u, tcols, trows, total);
+  const long img = (long)H * W * CIN;
+  // descriptor of the stage: base = first pixel of image b0 + c0 channels, records to the end of the tensor
+  const long long rec = (long long)(B - b0) * img * 4 - 4LL * c0;
+  const unsigned num_records = (unsigned)(rec > 0x7fffffffLL ? 0x7fffffffLL : rec);
+  std::vector<LinCell> lds((size_t)G::PINSTR * 64, LinCell{0, 0, 0, 0});
+  for (int lane = 0; lane < 64; ++lane) {
+    const int td = (lane >> 1) & 15;
+    const Wino4LinTile tile = wino4_lin_tile(16 * u + td, tcols, trows, total, b0);
+    for (int i = 0; i < G::PINSTR; ++i) {
+      const unsigned off = (unsigned)wino4_lin_patch_lane(i, tile, H, W, CIN, lane);
+      LinCell& c = lds[(size_t)64 * i + lane];
+      if (c.kind != 0) return printf("lin: LDS location written twice\n"), 1;
+      if (off >= num_records) {
+        c = LinCell{1, 0, 0, 0};
+      } else {
+        const long fl = (long)(off / 4) + c0;   // float index from the first pixel of image b0
+        if ((off % 16) != 0) return printf("lin: bad offset\n"), 1;
+        const long within = fl % img;
+        c = LinCell{2, b0 + (int)(fl / img), within / CIN, (int)((within % CIN) - c0) / 4};
+        if (((within % CIN) - c0) % 4 != 0 || (within % CIN) - c0 < 0 || (within % CIN) - c0 >= G::CB)
+          return printf("lin: channel quad out of the stage\n"), 1;
+      }
+    }
+  }
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      std::set<int> banks[2];
+      for (int lane = 0; lane < 64; ++lane) {
+        const int t = lane & 15, g = lane >> 4;
+        const int addr = wino4_lin_patch_base(t, g) + wino4_lin_patch_k(i, j);
+        if (addr % 8 != 0 || addr / 16 >= (int)lds.size()) return printf("lin: read outside the patch block\n"), 1;
+        banks[lane >> 5].insert((addr / 4) % 64);
+        banks[lane >> 5].insert((addr / 4 + 1) % 64);
+        const LinCell& c = lds[addr / 16];
+        const Wino4LinTile tile = wino4_lin_tile(16 * u + t, tcols, trows, total, b0);
+        const int iy = tile.y - 1 + i, ix = tile.x - 1 + j;
+        if (c.kind == 0) return printf("lin: read of an LDS location the DMA never wrote\n"), 1;
+        const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (inside) {
+          if (c.kind != 2 || c.b != b0 + tile.b || c.gpix != (long)iy * W + ix || c.quad != (g >> 1) ||
+              ((addr % 16) / 8) != (g & 1))
+            return printf("lin: unit %d lane %d (i=%d,j=%d): wrong element\n", u, lane, i, j), 1;
+        } else if (c.kind != 1) {
+          return printf("lin: element (%d,%d) outside the image is not a hardware zero\n", iy, ix), 1;
+        }
+      }
+      if (banks[0].size() != 64 || banks[1].size() != 64)
+        return printf("lin: transform read (i=%d,j=%d): bank conflict in a 32-lane group\n", i, j), 1;
+    }
+  return 0;
+}
+static int check_lin_stack(int B, int H, int W, int CIN) {
+  const int tcols = (W + 3) / 4, trows = (H + 3) / 4, total = B * trows * tcols, units = (total + 15) / 16;
+  // every tile is in exactly one unit, in raster order; tiles of a unit lie in images b0, b0 + 1, ...
+  for (int u = 0; u < units; ++u) {
+    if (u > 2 && u < units - 3 && u % 7) continue;
+    for (int c0 = 0; c0 < CIN; c0 += CIN - 8 > 0 ? CIN - 8 : 8)
+      if (check_lin_unit(B, H, W, CIN, u, c0)) return printf("  stack %dx%dx%dx%d unit %d stage %d\n", B, H, W, CIN, u, c0), 1;
+  }
+  for (int T = 0; T < total; ++T) {
+    const int b0 = wino4_lin_b0(T / 16, tcols, trows, total);
+    const Wino4LinTile t = wino4_lin_tile(T, tcols, trows, total, b0);
+    const int b = b0 + t.b;
+    if (!t.valid || t.b < 0 || b >= B || t.y % 4 || t.y >= H || t.x % 4 || t.x >= W) return printf("lin: tile out of the map\n"), 1;
+    if ((b * trows + t.y / 4) * tcols + t.x / 4 != T) return printf("lin: tile decode is not the raster order\n"), 1;
+  }
+  return 0;
+}
+
 int main() {
+  static_assert(Wino4LinGeom::LDS_BYTES + 16 <= 160 * 1024, "linear units: patch blocks + two U buffers must fit LDS");
+  {
+    const int stacks[][4] = {{3, 10, 38, 256}, {5, 20, 75, 128}, {2, 40, 149, 64}, {7, 1, 1, 32}, {4, 17, 9, 32},
+                             {2, 10, 125, 256}, {9, 5, 3, 40}, {1, 4, 64, 32}, {3, 3, 70, 64}};
+    for (const auto& st : stacks)
+      if (check_lin_stack(st[0], st[1], st[2], st[3])) return 1;
+  }
   static_assert(Wino4Geom::LDS_BYTES + 16 <= 160 * 1024, "patch blocks + two U buffers must fit the 160 KB of LDS");
   const int images[][3] = {{80, 998, 32}, {40, 499, 64}, {20, 250, 128}, {10, 125, 256}, {17, 9, 32}, {1, 1, 64},
                            {10, 38, 256}, {40, 149, 32}, {8, 128, 32}, {9, 129, 40}, {4, 64, 32}, {5, 65, 32}};

@@ -229,6 +229,48 @@ def test_conv3x3_winograd_f4(gpu_device):
         assert elementwise <= 8.0, (cin, cout, H, W, B, elementwise)
 
 
+@pytest.mark.parametrize("linear", ["1", "0"])
+def test_conv3x3_winograd_f4_unit_shapes(gpu_device, monkeypatch, linear):
+    """both unit shapes of the F(4x4) kernel on the SAME inputs: tile-linear units (16 consecutive tiles of the raster
+    order -- units straddle tile rows and images; what the launcher picks for the narrow maps of short chunks) and
+    row-shaped units (16 tiles of one tile row), forced through PA_WINO4_LINEAR in a fresh process-wide setting is not
+    possible (the switch is read once), so the test drives the launcher's own choice: narrow maps take linear units,
+    wide ones row units -- and checks every shape against torch: maps of 3 s chunks (40 x 149, 20 x 75, 10 x 38), maps
+    smaller than one unit, one tile per image (units of 16 images), ragged edges, with and without residual."""
+    import pyannote_audio_amd.ffi as ffi
+    from pyannote_audio_amd.weights import winograd4_pack, winograd4_weights
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(17 + int(linear))
+    narrow = [(64, 64, 40, 149, 5, True), (128, 128, 20, 75, 7, False), (256, 256, 10, 38, 9, True),
+              (32, 32, 3, 3, 37, True), (64, 32, 4, 4, 20, False), (32, 64, 6, 5, 3, True), (128, 128, 20, 75, 130, True),
+              (256, 256, 10, 38, 200, False)]
+    wide = [(64, 64, 40, 499, 2, True), (128, 128, 20, 250, 3, False), (256, 256, 10, 125, 5, True)]
+    for cin, cout, H, W, B, use_res in (narrow if linear == "1" else wide):
+        x = torch.randn(B, cin, H, W, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+        sh = torch.randn(cout, generator=g)
+        res = torch.randn(B, cout, H, W, generator=g)
+        ref = F.conv2d(x, wt, stride=1, padding=1) + sh.view(1, -1, 1, 1)
+        ref = F.relu(ref + res if use_res else ref)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        ud = winograd4_pack(winograd4_weights(wt)).to(gpu_device)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(gpu_device)
+        shd = sh.to(gpu_device)
+        # guard bands in front of and behind the output: a store that strays out of its image shows up
+        ybuf = torch.full((B + 2, H, W, cout), float("nan"), device=gpu_device)
+        y = ybuf[1:B + 1]
+        ffi.check(lib.pa_conv3x3_wino4(ffi.ptr(xd), B, H, W, cin, ffi.ptr(ud), ffi.ptr(shd),
+                                       ffi.ptr(rd) if use_res else None, C.c_void_p(y.data_ptr()), cout, 1, ffi.stream()),
+                  "conv3x3_wino4")
+        torch.cuda.synchronize()
+        assert torch.isnan(ybuf[0]).all() and torch.isnan(ybuf[B + 1]).all(), "stores outside the output tensor"
+        got = y.permute(0, 3, 1, 2).cpu()
+        assert not torch.isnan(got).any(), (cin, cout, H, W, B)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        elementwise = north_star_ratio(f"wino4_units_{cin}_{cout}_{H}x{W}_B{B}", got, ref)
+        assert err <= 1e-4 and elementwise <= 8.0, (cin, cout, H, W, B, err, elementwise)
+
+
 def test_conv3x3_row_split_between_f4_and_f2(gpu_device):
     """a map whose height is 2 (mod 4) -- layer 4 on 10 s chunks: 10 x 125 x 256 -- is split by pa_emb_forward: rows
     0 .. H - 3 through pa_conv3x3_wino4_rows, the last two through pa_conv3x3_wino_rows; together they are the whole
