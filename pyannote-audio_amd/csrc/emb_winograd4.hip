@@ -171,6 +171,9 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 #ifndef PA_W4_DEFER_STORES   // stores of channel group 0 issued from inside the column arithmetic of group 1:
 #define PA_W4_DEFER_STORES 1 // 0 = never, 1 = instantiation without residual only, 2 = both (spills: slower)
 #endif
+#ifndef PA_W4_LATE_BARRIER   // the stage barrier behind most of the input transform (0: in front of it, as in round 4)
+#define PA_W4_LATE_BARRIER 1
+#endif
 #ifndef W4_ROWS_PER_REGION   // rows of the transform's second pass between two scheduling barriers (1, 2, 3 or 6)
 #define W4_ROWS_PER_REGION 1
 #endif
@@ -369,15 +372,26 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   while (true) {
     for (int s = 0; s < nstages; ++s) {
       W4_STAMP(0);
+      // LATE BARRIER (round 5).  A stage needs its own PATCH for the input transform and everybody's U pieces only for
+      // the MFMA run.  The patch pieces of a stage are issued in front of its U pieces and loads complete in order, so
+      // vmcnt(9) -- this wave's 9 U pieces may still fly -- is "my patch has landed"; the full wait and the workgroup
+      // barrier (everybody's U pieces have landed, everybody is done with the other U buffer) move behind the
+      // transform's column pass and first rows, which hide what is left of the U flight and of the waves' skew.  A
+      // tile's first stage still waits for everything here: the epilogue's stores and residual loads were issued
+      // behind its staging.  (PA_W4_LATE_BARRIER=0: round 4's order, barrier in front of the transform.)
+#if PA_W4_LATE_BARRIER
+      if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
+#endif
       W4_STAMP(1);
       // the claim of the NEXT group was issued at the start of this tile: its value is picked up here, behind the
       // wait above (anywhere else the compiler's own vmcnt wait for it would also wait for staging in flight), and
-      // published by the barrier that opens the tile's last stage
+      // published by the barrier of the tile's last stage
       if (s == nstages - 1 && tid == 0) mail[0] = tq_resolve(tq, claim);
-      // the first column of the transform's patch reads goes out in FRONT of the barrier (the patch is this wave's own:
-      // its DMA has landed with the wait above), so that their latency overlaps the barrier instead of opening the
-      // transform; the barrier's own LDS wait comes before them
+      // the first column of the transform's patch reads goes out in FRONT of everything else (the patch is this wave's
+      // own: its DMA has landed with the wait above); the LDS wait in front of them covers the mailbox store
       f32x2 x_first[6];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if !defined(PA_W4_NOPATCHREAD) && !defined(PA_W4_NOTRANSFORM)
@@ -385,38 +399,48 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       for (int i = 0; i < 6; ++i)
         x_first[i] = w4_lds_read64(my_patch + pbase0 + (LIN ? wino4_lin_patch_k(i, 0) : wino4_patch_k(i, 0)));
 #endif
-      __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done with the other buffer
-      asm volatile("" ::: "memory");
-      W4_STAMP(2);
       unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
       unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
       // what the MFMA run below stages: the next stage of this unit, or the first stage of the next group's unit
       bool stage_next = true;
       Wino4Stage nst;
-
-      if (s + 1 < nstages) {
-        nst = wino4_stage(cctx, U, COUT, CIN, s + 1, my_patch, uother);
-      } else {
-        nq = mail[0];   // (written by thread 0 in front of this stage's barrier)
-        stage_next = nq >= 0;
-        wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups);
-        nxt_n0 = wk.n0;
-        if constexpr (LIN) {
-          // (the next unit's 18 lane offsets are computed behind the transform, where the registers are free)
-          lnxt.b0 = __builtin_amdgcn_readfirstlane(wino4_lin_b0(wk.unit0 + slw, cgroups, trows, num_units));
-          nctx = wino4_lin_ctx(X, H, W, CIN, nimg, lnxt.b0, nxt_n0);
+      // the stage barrier + everything that needs it (the mailbox of the tile's last stage)
+      auto stage_barrier = [&]() {
+#if PA_W4_LATE_BARRIER
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's U pieces
+#endif
+        __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done with the other buffer
+        asm volatile("" ::: "memory");
+        W4_STAMP(2);
+        if (s + 1 < nstages) {
+          nst = wino4_stage(cctx, U, COUT, CIN, s + 1, my_patch, uother);
         } else {
-          nxt = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
-          nxt.valid &= wk.valid;
-          nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
+          nq = mail[0];   // (written by thread 0 in front of this stage's barrier)
+          stage_next = nq >= 0;
+          wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups);
+          nxt_n0 = wk.n0;
+          if constexpr (LIN) {
+            // (the next unit's 18 lane offsets are computed behind the transform, where the registers are free)
+            lnxt.b0 = __builtin_amdgcn_readfirstlane(wino4_lin_b0(wk.unit0 + slw, cgroups, trows, num_units));
+            nctx = wino4_lin_ctx(X, H, W, CIN, nimg, lnxt.b0, nxt_n0);
+          } else {
+            nxt = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
+            nxt.valid &= wk.valid;
+            nctx = wino4_ctx(X, H, W, CIN, nxt, nxt_n0, x0_last);
+          }
+          nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
         }
-        nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
-
-      }
+      };
+#if !PA_W4_LATE_BARRIER
+      stage_barrier();
+#endif
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
       f32x2 uf_first[2][2];   // (U fragments of the first point pair, read inside the transform)
 #ifdef PA_W4_NOTRANSFORM   // development A/B (timing only): no reads, no arithmetic
+#if PA_W4_LATE_BARRIER
+      stage_barrier();
+#endif
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -458,6 +482,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
         for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
           if (i + W4_ROWS_PER_REGION >= 6) {
+#if PA_W4_LATE_BARRIER
+            stage_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             // the U fragments of the MFMA run's first point pair go out in front of the transform's last row(s):
             // their LDS latency no longer opens the run
 #pragma unroll
