@@ -109,6 +109,30 @@ def all_gather_chunks(seg_local, emb_local, total_chunks: int, shard: Shard, dev
     return unpack_records(torch.cat(parts, dim=0), F, S, D)
 
 
+def broadcast_object(obj, src: int, shard: Shard, group, device: torch.device):
+    """a small picklable object (the cluster labels and centroids of a joint job: numpy arrays) from rank `src` to
+    every rank of `group`: its size, then its bytes (two broadcasts; with RCCL through device memory).  The ranks
+    trust each other: this is the process group of ONE job."""
+    import io
+    import pickle
+    wire = _wire_device(shard, device)
+    if shard.rank == src:
+        buf = io.BytesIO()
+        pickle.dump(obj, buf, protocol=pickle.HIGHEST_PROTOCOL)
+        payload = torch.frombuffer(bytearray(buf.getvalue()), dtype=torch.uint8)
+        size = torch.tensor([payload.numel()], dtype=torch.int64, device=wire)
+    else:
+        payload = None
+        size = torch.zeros(1, dtype=torch.int64, device=wire)
+    dist.broadcast(size, src=src, group=group)
+    n = int(size.item())
+    data = payload.to(wire) if shard.rank == src else torch.empty(n, dtype=torch.uint8, device=wire)
+    dist.broadcast(data, src=src, group=group)
+    if shard.rank == src:
+        return obj
+    return pickle.loads(data.cpu().numpy().tobytes())
+
+
 # ---------------------------------------------------------------------------------------------------
 # many files per rank: ONE all-gather of {header, records} buffers whose size every rank derives from what it
 # has SEEN in earlier headers -- never from local information, so no rank can leave the collective alone

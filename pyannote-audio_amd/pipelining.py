@@ -1,4 +1,4 @@
-"""Two-stage software pipeline of the batch forms of `SpeakerDiarization` (`apply_batch`, `apply_joint_batches`).
+"""Software pipelines of the batch forms of `SpeakerDiarization` (`apply_batch`, `apply_joint_batches`).
 
     front(item i+1)   main thread / stream 0:   |-- segmentation --|------ embeddings ------|
     tail(item i)      worker thread / stream 1:                     |-- clustering, back end --|
@@ -53,3 +53,59 @@ def pipelined(items: Iterable[Any], front: Callable[[Any, Callable[[], None]], A
 
 def _nothing() -> None:
     pass
+
+
+def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], None]], Any],
+                    solve: Callable[[Any], Any], share: Callable[[int, int, Any, Any], Any],
+                    finish: Callable[[Any, Any], Any], rank: int, world: int, depth: int = 0,
+                    gate_timeout: float = 5.0) -> Iterator[Tuple[Any, Any]]:
+    """Jobs whose expensive middle step is needed by every rank but has to be COMPUTED only once (the joint
+    clustering of BASELINE.json configs[4]: every rank needs the cluster labels, one rank can make them).
+
+        main thread      front(job j, release)          in job order (its collectives stay in this thread)
+        solver thread    solve(state j)                 only on the OWNER of job j = rank j % world
+        tail thread      share(j, owner, state, solution or None) -> solution on every rank
+                         finish(state, solution)        in job order (the collectives of `share` stay in this thread,
+                                                        in the same order on every rank)
+
+    With the solve step done redundantly on every rank a stream of jobs runs at max(front, solve) per job; with owners
+    it runs at max(front, solve / world): rank r solves job r while the other ranks' fronts and solves go on, and its
+    tail thread picks the results up in order.  Up to `depth` jobs (default world + 1) are in flight before the main
+    thread waits for the oldest; results come back in input order.  `solve` of job j starts when the front of job j + 1
+    has called `release()` -- or has returned, or does not exist (as `pipelined`: the solve step must not run beside
+    the first stage of the next front).  Pure host logic: tests/test_pipelining_cpu.py."""
+    depth = depth or world + 1
+    log = logging.getLogger(__name__)
+
+    def gated_solve(state, gate: threading.Event):
+        if not gate.wait(timeout=gate_timeout):
+            log.warning("pipelined_owned: a solve step was not released within %.1f s and runs ungated", gate_timeout)
+        return solve(state)
+
+    def tail(j: int, state, solved):
+        owner = j % world
+        solution = solved.result() if solved is not None else None     # (re-raises what `solve` raised)
+        return finish(state, share(j, owner, state, solution))
+
+    with ThreadPoolExecutor(max_workers=1) as solver, ThreadPoolExecutor(max_workers=1) as tails:
+        in_flight = []          # (item, tail future), oldest first
+        gate = None             # gate of the newest job's solve step
+        try:
+            for j, item in enumerate(items):
+                state = front(item, gate.set if gate is not None else _nothing)
+                if gate is not None:
+                    gate.set()
+                gate = threading.Event()
+                solved = solver.submit(gated_solve, state, gate) if j % world == rank else None
+                in_flight.append((item, tails.submit(tail, j, state, solved)))
+                while len(in_flight) > depth:
+                    done_item, fut = in_flight.pop(0)
+                    yield done_item, fut.result()
+            if gate is not None:
+                gate.set()
+            while in_flight:
+                done_item, fut = in_flight.pop(0)
+                yield done_item, fut.result()
+        finally:
+            if gate is not None:
+                gate.set()

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 import textwrap
 import time
 import warnings
@@ -40,7 +41,7 @@ from .diarization import optimal_mapping, set_num_speakers, to_annotation
 from .inference import Inference
 from .model import Model
 from .pipeline import ParamDict, Pipeline, Uniform
-from .pipelining import pipelined
+from .pipelining import pipelined, pipelined_owned
 from .speaker_verification import PipelineModel, PretrainedSpeakerEmbedding, get_model
 
 
@@ -534,8 +535,55 @@ class SpeakerDiarization(Pipeline):
                 side.synchronize()
             return out
 
-        for _, out in pipelined(groups, gather, finish, self.TAIL_GATE_TIMEOUT):
+        shard = parallel.shard_from_env() if parallel.current_shard().world_size == 1 else parallel.Shard()
+        if shard.world_size == 1 or os.environ.get("PA_JOINT_OWNERS", "1") == "0":
+            for _, out in pipelined(groups, gather, finish, self.TAIL_GATE_TIMEOUT):
+                yield out
+            return
+
+        # Several ranks: every rank needs the labels of job j, ONE rank has to compute them.  Done redundantly (above)
+        # a stream of jobs runs at max(front end, clustering) per job -- 8 one-hour files: 0.78 s against 1.29 s, the
+        # clustering sets the pace (profiles/r4_projected_n8.txt).  With owners (job j is clustered by rank j % world
+        # on a third stream while its main stream goes on with the front ends, and the labels are broadcast over a
+        # second process group in the tail thread) it runs at max(front end, clustering / world): the front end sets
+        # the pace from two ranks on.  pipelining.pipelined_owned has the schedule.
+        group = self._label_group(shard)
+        solving = torch.cuda.Stream(device=device)
+
+        def solve(job):
+            if job["empty"] or not len(job["all_emb"]):
+                return None
+            with torch.cuda.device(device), torch.cuda.stream(solving):
+                solution = self._joint_cluster(job, bounds)
+                solving.synchronize()
+            return solution
+
+        def share(j, owner, job, solution):
+            return parallel.broadcast_object(solution, owner, shard, group, device)
+
+        def back_ends(job, solution):
+            with torch.cuda.device(device), torch.cuda.stream(side):
+                if solution is None:
+                    out = [(fr.file, self._empty_output(fr.file)) for fr in job["fronts"]]
+                else:
+                    out = list(self._joint_back_ends(job, solution[0], solution[1], bounds))
+                side.synchronize()
+            return out
+
+        for _, out in pipelined_owned(groups, gather, solve, share, back_ends, shard.rank, shard.world_size,
+                                      gate_timeout=self.TAIL_GATE_TIMEOUT):
             yield out
+
+    def _label_group(self, shard):
+        """the process group of the label broadcasts (the tail thread's collectives must not share a communicator
+        with the main thread's record exchange); created once per default process group, by every rank together"""
+        import torch.distributed as dist
+        world = dist.group.WORLD
+        cached = getattr(self, "_label_group_cache", None)
+        if cached is None or cached[0] is not world:
+            cached = (world, dist.new_group(list(range(shard.world_size)), backend=dist.get_backend(shard.group)))
+            self._label_group_cache = cached
+        return cached[1]
 
     def _joint_gather(self, files: List[dict], hook, device: torch.device,
                       after_segmentation: Optional[Callable] = None) -> dict:
@@ -582,13 +630,17 @@ class SpeakerDiarization(Pipeline):
 
     def _joint_finish(self, job: dict, bounds):
         """second half: ONE clustering over all records, then the back end of every local file"""
-        num_speakers, min_speakers, max_speakers = bounds
-        fronts, hooks = job["fronts"], job["hooks"]
         if job["empty"]:
-            for fr in fronts:
+            for fr in job["fronts"]:
                 yield fr.file, self._empty_output(fr.file)
             return
-        all_seg, all_emb, sizes, mine = job["all_seg"], job["all_emb"], job["sizes"], job["mine"]
+        hard, centroids = self._joint_cluster(job, bounds)
+        yield from self._joint_back_ends(job, hard, centroids, bounds)
+
+    def _joint_cluster(self, job: dict, bounds):
+        """the ONE clustering of a joint job over the records of all files of all ranks -> (hard, centroids)"""
+        num_speakers, min_speakers, max_speakers = bounds
+        all_seg, all_emb = job["all_seg"], job["all_emb"]
         _, clean = frame_ops.chunk_stats(all_seg)
         # the clustering only reads the SHAPE of the segmentations when the clean-frame counts are given
         seg_view = SlidingWindowFeature(all_seg.cpu().numpy(), self._chunk_grid())
@@ -596,6 +648,12 @@ class SpeakerDiarization(Pipeline):
             embeddings=all_emb, segmentations=seg_view, num_clusters=num_speakers,
             min_clusters=min_speakers, max_clusters=max_speakers, frames=self._frames,
             num_clean_frames=clean.cpu().numpy(), device_embeddings=job.get("all_emb_dev"))
+        return hard, centroids
+
+    def _joint_back_ends(self, job: dict, hard, centroids, bounds):
+        """the back end of every local file of a joint job, given the job's cluster labels"""
+        _, min_speakers, max_speakers = bounds
+        fronts, hooks, sizes, mine = job["fronts"], job["hooks"], job["sizes"], job["mine"]
         offsets = np.concatenate([[0], np.cumsum(sizes)])
         self.joint_hard_clusters = hard                # (sum C, S): kept for inspection / tests
         self.joint_sizes = sizes

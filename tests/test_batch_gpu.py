@@ -145,9 +145,11 @@ def _joint_worker(rank, world, port, pipeline_dir, specs, q):
            for f, o in pipeline.apply_batch(mine, joint_clustering=True)]
     # the same job twice through the pipelined form (what bench.py --gpus N runs): collectives stay in the main
     # thread, in the same order on every rank; the clustering / back ends run in the worker thread
-    again = [[(f["uri"], _turns(o.speaker_diarization)) for f, o in job]
-             for job in pipeline.apply_joint_batches([_files(specs[rank]), _files(specs[rank])])]
-    assert again[0] == again[1] == [(u, t) for u, t, _ in res]
+    # with several ranks job j is clustered by rank j % world only (pipelining.pipelined_owned) and its labels are
+    # broadcast: three jobs, so that rank 0 owns two of them and every rank is a receiver at least once
+    again = [[(f["uri"], _turns(o.speaker_diarization), o.speaker_embeddings.tolist()) for f, o in job]
+             for job in pipeline.apply_joint_batches([_files(specs[rank]) for _ in range(3)])]
+    assert again[0] == again[1] == again[2] == res
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()

@@ -101,6 +101,14 @@ def _worker(rank, world, port, total, q, port2=None):
         ok = False
     except ValueError as err:
         ok = ok and "different record sizes" in str(err)
+    # the label broadcast of a joint job (pipelining.pipelined_owned): numpy arrays / None from one rank to all
+    side = dist.new_group(list(range(world)), backend="gloo")
+    for src in range(world):
+        obj = (np.arange(12, dtype=np.int8).reshape(4, 3) * (src + 1), rng.standard_normal((2, 5))) if src == rank else None
+        got = parallel.broadcast_object(obj, src, shard, side, torch.device("cpu"))
+        ok = ok and got[0].dtype == np.int8 and np.array_equal(got[0], np.arange(12, dtype=np.int8).reshape(4, 3) * (src + 1)) \
+            and got[1].shape == (2, 5)
+    ok = ok and parallel.broadcast_object(None if rank == 1 else "x", 1, shard, side, torch.device("cpu")) is None
     q.put((rank, b, e, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

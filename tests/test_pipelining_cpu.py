@@ -108,3 +108,91 @@ def test_a_gate_that_times_out_is_logged(caplog):
         out = list(pipelined([0, 1], front, tail, gate_timeout=0.05))
     assert out == [(0, 0), (1, 10)]
     assert any("not released within" in r.getMessage() for r in caplog.records)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# pipelined_owned: jobs whose middle step is computed by ONE rank (job j -> rank j % world) and shared with the others
+# ---------------------------------------------------------------------------------------------------------------
+def _owned_worker(rank, world, port, jobs, front_s, solve_s, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(list(range(world)), backend="gloo")     # the tail thread's collectives (as in the pipeline)
+    from pyannote_audio_amd.pipelining import pipelined_owned
+    solved_here = []
+
+    def front(item, release):
+        time.sleep(front_s / 4)
+        release()
+        time.sleep(3 * front_s / 4)
+        t = torch.tensor([item + 100 * rank], dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)                                   # the main thread's collective, in job order
+        return {"item": item, "seen": [int(g) for g in got]}
+
+    def solve(state):                                             # the expensive step: owners only
+        solved_here.append(state["item"])
+        time.sleep(solve_s)
+        return sum(state["seen"]) * 7
+
+    def share(j, owner, state, solution):
+        t = torch.tensor([solution if rank == owner else -1], dtype=torch.int64)
+        dist.broadcast(t, src=owner, group=side)
+        return int(t)
+
+    def finish(state, solution):
+        return state["item"], solution
+
+    t0 = time.perf_counter()
+    out = list(pipelined_owned(range(jobs), front, solve, share, finish, rank, world))
+    dt = time.perf_counter() - t0
+    q.put((rank, out, solved_here, dt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owned_solve_steps_are_shared_in_order_and_do_not_serialise():
+    """3 ranks over gloo, 9 jobs, solve = 4 x front: every rank gets every job's solution (computed once, by rank
+    j % 3), in order; the stream runs at about max(front, solve / world) per job -- far from the `solve` per job that a
+    redundant solve step (or a tail thread that waits for job j - 1's result before starting its own solve) costs."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world, jobs, front_s, solve_s = 3, 9, 0.05, 0.20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_owned_worker, args=(r, world, port, jobs, front_s, solve_s, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [(j, j, (3 * j + 100 * (0 + 1 + 2)) * 7) for j in range(jobs)]
+    for rank, out, solved_here, dt in res:
+        assert [(item, o[0], o[1]) for item, o in out] == want, rank
+        assert solved_here == [j for j in range(jobs) if j % world == rank]
+        # serialised it would take jobs * solve_s = 1.8 s; pipelined ~ jobs * max(front, solve / world) + one solve
+        assert dt < 0.6 * jobs * solve_s, (rank, dt)
+
+
+def test_owned_pipeline_surfaces_errors_and_single_rank_is_plain():
+    from pyannote_audio_amd.pipelining import pipelined_owned
+    out = list(pipelined_owned(range(5), lambda it, rel: it, lambda st: st * 2, lambda j, o, st, sol: sol,
+                               lambda st, sol: (st, sol), rank=0, world=1))
+    assert out == [(i, (i, 2 * i)) for i in range(5)]
+
+    def bad_solve(st):
+        if st == 2:
+            raise RuntimeError("solve failed")
+        return st
+
+    with pytest.raises(RuntimeError, match="solve failed"):
+        list(pipelined_owned(range(4), lambda it, rel: it, bad_solve, lambda j, o, st, sol: sol,
+                             lambda st, sol: sol, rank=0, world=1))
