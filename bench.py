@@ -555,7 +555,8 @@ def main():
                        "parallelism": f"file-per-gpu x{world}" + (", joint clustering" if joint else "")},
             "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
             "mode": ("configs[4]: one file per GPU and step, RCCL all-gather of the records, ONE joint "
-                     "clustering over all files (apply_batch(joint_clustering=True))") if joint else
+                     "clustering over all files per step -- computed by the step's owner rank (step % N), labels "
+                     "broadcast (apply_joint_batches / pipelining.pipelined_owned)") if joint else
                     ("sequential pipeline(file) calls" if args.sequential else
                      "pipeline([files]) = apply_batch: clustering/back end of file i overlap the front end "
                      "of file i+1" + (" (N independent per-file pipelines, no exchange)" if world > 1 else "")),

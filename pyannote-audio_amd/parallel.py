@@ -111,11 +111,12 @@ def all_gather_chunks(seg_local, emb_local, total_chunks: int, shard: Shard, dev
 
 def broadcast_object(obj, src: int, shard: Shard, group, device: torch.device):
     """a small picklable object (the cluster labels and centroids of a joint job: numpy arrays) from rank `src` to
-    every rank of `group`: its size, then its bytes (two broadcasts; with RCCL through device memory).  The ranks
-    trust each other: this is the process group of ONE job."""
+    every rank of `group`: its size, then its bytes (two broadcasts; through device memory when `group` is an RCCL
+    group, through host memory -- where the labels live anyway -- when it is a gloo group).  The ranks trust each
+    other: this is the process group of ONE job."""
     import io
     import pickle
-    wire = _wire_device(shard, device)
+    wire = device if (dist.get_backend(group) == "nccl" and device.type == "cuda") else torch.device("cpu")
     if shard.rank == src:
         buf = io.BytesIO()
         pickle.dump(obj, buf, protocol=pickle.HIGHEST_PROTOCOL)

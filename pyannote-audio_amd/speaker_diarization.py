@@ -576,12 +576,15 @@ class SpeakerDiarization(Pipeline):
 
     def _label_group(self, shard):
         """the process group of the label broadcasts (the tail thread's collectives must not share a communicator
-        with the main thread's record exchange); created once per default process group, by every rank together"""
+        with the main thread's record exchange); created once per default process group, by every rank together.
+        A GLOO group whatever the main backend is: the labels and centroids are host arrays of a few hundred KB, and a
+        host-side broadcast cannot interleave badly with the RCCL kernels of the record exchange that the main thread
+        launches at the same time on the same device."""
         import torch.distributed as dist
         world = dist.group.WORLD
         cached = getattr(self, "_label_group_cache", None)
         if cached is None or cached[0] is not world:
-            cached = (world, dist.new_group(list(range(shard.world_size)), backend=dist.get_backend(shard.group)))
+            cached = (world, dist.new_group(list(range(shard.world_size)), backend="gloo"))
             self._label_group_cache = cached
         return cached[1]
 
