@@ -28,11 +28,11 @@ inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 // cost more than it gains.
 inline bool prefer_wino4(int H, int W, int cin) {
   auto up = [](int a, int b) { return (long)((a + b - 1) / b) * b; };
-  // (the F(4x4) launcher takes tile-linear units when they save more than 6 % of the units: they pad the map to whole
-  //  4x4 tiles only, at +3.5 % per stage)
+  // (the F(4x4) launcher takes tile-linear units when that leaves at least 1.2x fewer units: they pad the map to whole
+  //  4x4 tiles only, at ~1.2x the cost per unit -- emb_winograd4.hip: wino4_linear_wanted)
   long p4 = up(H, 4) * up(W, 64);
   const long p4_lin = up(H, 4) * up(W, 4);
-  if (p4_lin * 106 <= p4 * 100) p4 = p4_lin * 1035 / 1000;
+  if (p4_lin * 120 <= p4 * 100) p4 = p4_lin * 120 / 100;
   long p2 = up(H, 8) * up(W, 32);
   if (up(H, 4) * up(W, 64) < p2) p2 = up(H, 4) * up(W, 64);
   if (up(H, 2) * up(W, 128) < p2) p2 = up(H, 2) * up(W, 128);

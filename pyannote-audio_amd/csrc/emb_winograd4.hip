@@ -792,15 +792,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 }
 
 // row-shaped units pad every tile row to whole groups of 16 tiles, tile-linear units only the end of the launch, but
-// stage 18 instead of 13 patch pieces per stage (+ ~3.5 % per stage, profiles/r5_wino4_linear_units.txt): linear when
-// that saves more than it costs.  PA_WINO4_LINEAR=0 / 1 forces one of them (A/B aid).
+// their tiles do not share halos: 18 instead of 13 patch pieces and 45 % more patch bytes per stage -- a unit costs
+// 1.14x (256 channels) to 1.24x (64 channels) as much (profiles/r5_wino4_linear_units.txt).  Linear when it has at least
+// 1.2x fewer units.  PA_WINO4_LINEAR=0 / 1 forces one of them (A/B aid).
 static bool wino4_linear_wanted(int B, int H, int W, int rows) {
   if (rows != H) return false;                      // (row ranges: the row-shaped kernel)
   static const char* e = getenv("PA_WINO4_LINEAR");
   if (e != nullptr) return atoi(e) != 0;
   const long tcols = cdiv(W, 4), trows = cdiv(H, 4);
   const long lin_units = cdiv((long)B * trows * tcols, 16), row_units = (long)B * trows * cdiv(W, 64);
-  return lin_units * 106 <= row_units * 100;
+  return lin_units * 120 <= row_units * 100;
 }
 
 template <bool HAS_R, bool LIN>
