@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ R, float* __restrict__ Y,
                                                     int Ho, int Wo, int COUT, int relu, int tiles_w,
-                                                    int tiles_hw, int n_tiles, int total_tiles,
+                                                    int tiles_hw, int n_tiles, int total_tiles, int xranges,
                                                     int* __restrict__ counters) {
   using G = ConvGeom<S, TH, TWT>;
   constexpr int MT = TH * TWT;   // 32-pixel M-tiles per workgroup
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
   // fetched it from HBM -- 2.07x the algorithmic bytes, profiles/r4_traffic.json.)  (pixel tile, image) pair
   // pb = (r / n_tiles) * 8 + xcd; the index space is padded to whole XCD stripes, pairs >= num_pb are holes.
   const int num_pb = total_tiles / n_tiles;
-  auto pair_of = [&](int t) { return ((t >> 3) / n_tiles) * 8 + (t & 7); };
+  auto pair_of = [&](int t) {
+    return xranges ? (t & 7) * ((num_pb + 7) >> 3) + (t >> 3) / n_tiles : ((t >> 3) / n_tiles) * 8 + (t & 7);
+  };
   auto decode = [&](int t) {
     Tile q;
     const int pb = pair_of(t);
@@ -406,6 +408,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
   if (tid == 0) tq_done(tq, gridDim.x);
 }
 
+int xcd_ranges_wanted(bool by_default);   // emb_winograd4.hip
+
 template <int S, int TH, int TWT, int BN, bool HAS_R>
 static int launch_conv_r(const float* X, int B, int H, int W, int CIN, const float* Wg,
                          const float* shift, const float* R, float* Y, int COUT, int relu,
@@ -442,7 +446,8 @@ static int launch_conv_r(const float* X, int B, int H, int W, int CIN, const flo
     return 2;
   }
   hipLaunchKernelGGL((k_conv3x3<S, TH, TWT, BN, HAS_R>), dim3(grid), dim3(256), lds, st, X, H, W, CIN, Wg,
-                     shift, R, Y, Ho, Wo, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, counters);
+                     shift, R, Y, Ho, Wo, COUT, relu, tiles_w, tiles_hw, n_tiles, (int)total, xcd_ranges_wanted(true),
+                     counters);
   return 0;
 }
 

@@ -355,7 +355,7 @@ template <int TR, int TCG, bool HAS_R>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT,
-    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb, int y_first,
+    int relu, int tiles_w, int tiles_hw, int n_tiles, int total_tiles, int num_pb, int y_first, int xranges,
     int* __restrict__ counters) {
   using G = WinoGeom<TR, TCG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
         wino_patch_lanes<TR, TCG>(prel, W, CIN, lane_v, slw, x0_last);
         wino_patch_bases<TR, TCG>(pbase, lane_v & 15, lane_v >> 4, wr, wc);
       }
-      const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb, y_first);
+      const WinoTile cur = wino_decode(q, tiles_w, tiles_hw, n_tiles, 2 * TR, 32 * TCG, num_pb, y_first, xranges);
       if (tid == 0) ahead = tq_claim_own(tq);
       for (int c0 = 0; c0 < CIN; c0 += WCB) {
         WINO_STAMP(0);
@@ -482,6 +482,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wino(
   if (tid == 0) tq_done(tq, gridDim.x);
 }
 
+int xcd_ranges_wanted(bool by_default);   // emb_winograd4.hip
+
 template <int TR, int TCG, bool HAS_R>
 static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                          const float* R, float* Y, int COUT, int relu, int y_first, hipStream_t st) {
@@ -520,7 +522,7 @@ static int launch_wino_r(const float* X, int B, int H, int W, int CIN, const flo
     return 2;
   }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, tiles_w,
-                     tiles_hw, n_tiles, (int)total, (int)num_pb, y_first, counters);
+                     tiles_hw, n_tiles, (int)total, (int)num_pb, y_first, xcd_ranges_wanted(true), counters);
   return 0;
 }
 
@@ -547,7 +549,7 @@ template <bool HAS_R>
 __global__ __launch_bounds__(512) void k_conv3x3_wino32(
     const float* __restrict__ X, int H, int W, const float* __restrict__ U, const float* __restrict__ shift,
     const float* __restrict__ R, float* __restrict__ Y, int relu, int tiles_w, int tiles_hw, int total_tiles,
-    int num_pb, int* __restrict__ counters) {
+    int num_pb, int xranges, int* __restrict__ counters) {
   using G = WinoGeom<4, 1>;
   constexpr int CIN = 32, COUT = 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino32(
   int q = mail[half];          // tile being staged / computed by this half (-1: none left)
   int done_q = -1;             // tile whose accumulators are waiting for their epilogue
   int ahead = 0;
-  WinoTile cur = wino_decode(q < 0 ? 0 : q, tiles_w, tiles_hw, 1, 8, 32, num_pb), fin = cur;
+  WinoTile cur = wino_decode(q < 0 ? 0 : q, tiles_w, tiles_hw, 1, 8, 32, num_pb, 0, xranges), fin = cur;
   if (q >= 0) {
     wino_issue_patch<4, 1>(X, H, W, CIN, cur, 0, patch, prel, slw, x0_last);
     wino_issue_patch<4, 1>(X, H, W, CIN, cur, WCB, patch + G::PATCH, prel, slw, x0_last);
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino32(
       }
       q = qn;
       if (q >= 0) {
-        cur = wino_decode(q, tiles_w, tiles_hw, 1, 8, 32, num_pb);
+        cur = wino_decode(q, tiles_w, tiles_hw, 1, 8, 32, num_pb, 0, xranges);
         wino_issue_patch<4, 1>(X, H, W, CIN, cur, 0, patch, prel, slw, x0_last);
         wino_issue_patch<4, 1>(X, H, W, CIN, cur, WCB, patch + G::PATCH, prel, slw, x0_last);
         if (leader) ahead = tq_claim_own(tq);
@@ -665,7 +667,7 @@ static int launch_wino32(const float* X, int B, int H, int W, const float* U, co
     return 2;
   }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, st, X, H, W, U, shift, R, Y, relu, tiles_w, tiles_hw,
-                     (int)total, (int)num_pb, counters);
+                     (int)total, (int)num_pb, xcd_ranges_wanted(true), counters);
   return 0;
 }
 

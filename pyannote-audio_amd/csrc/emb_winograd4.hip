@@ -300,7 +300,7 @@ template <bool HAS_R, bool LIN>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT, int relu,
-    int cgroups, int trows, int num_units, int num_groups, int n_tiles, int total_work, int nimg,
+    int cgroups, int trows, int num_units, int num_groups, int n_tiles, int total_work, int nimg, int xranges,
     int* __restrict__ counters) {
   using G = std::conditional_t<LIN, Wino4LinGeom, Wino4Geom>;
   constexpr int PIN = G::PINSTR;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 
   // this wave's unit of the claimed group (a group past the end / a unit past the last one is computed on the last
   // real unit's data and not stored: valid = 0)
-  Wino4Work wk = wino4_decode(q, n_tiles, num_groups);
+  Wino4Work wk = wino4_decode(q, n_tiles, num_groups, xranges);
   Wino4Unit cur = Wino4Unit{0, 0, 0, 0}, nxt = cur;
   Wino4LinUnit lcur = Wino4LinUnit{0, Wino4LinTile{0, 0, 0, 0}}, lnxt = lcur;
   int cur_n0 = wk.n0, nxt_n0 = wk.n0;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         } else {
           nq = mail[0];   // (written by thread 0 in front of this stage's barrier)
           stage_next = nq >= 0;
-          wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups);
+          wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups, xranges);
           nxt_n0 = wk.n0;
           if constexpr (LIN) {
             // (the next unit's 18 lane offsets are computed behind the transform, where the registers are free)
@@ -804,6 +804,13 @@ static bool wino4_linear_wanted(int B, int H, int W, int rows) {
   return lin_units * 120 <= row_units * 100;
 }
 
+// tile order: contiguous ranges per XCD (neighbouring tiles share their halos in one L2) or round-robin;
+// PA_XCD_RANGES=0 / 1 forces one of them for every convolution kernel (A/B aid)
+int xcd_ranges_wanted(bool by_default) {
+  static const char* e = getenv("PA_XCD_RANGES");
+  return e != nullptr ? (atoi(e) != 0) : (by_default ? 1 : 0);
+}
+
 template <bool HAS_R, bool LIN>
 static int launch_wino4(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                         const float* R, float* Y, int COUT, int relu, int rows, hipStream_t st) {
@@ -838,7 +845,8 @@ static int launch_wino4(const float* X, int B, int H, int W, int CIN, const floa
   }
   // (tile-linear: the kernel's `num_units` argument carries the number of TILES)
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, st, X, H, W, CIN, U, shift, R, Y, COUT, relu, cgroups, trows,
-                     (int)(LIN ? total_tiles : num_units), (int)num_groups, n_tiles, (int)total, B, counters);
+                     (int)(LIN ? total_tiles : num_units), (int)num_groups, n_tiles, (int)total, B,
+                     xcd_ranges_wanted(n_tiles < 8), counters);
   return 0;
 }
 

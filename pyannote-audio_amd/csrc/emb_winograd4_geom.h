@@ -95,10 +95,19 @@ constexpr int wino4_u_k(int xi, int cg) { return 1024 * xi + 512 * cg; }
 struct Wino4Work {
   int unit0, n0, valid;
 };
-__device__ __forceinline__ Wino4Work wino4_decode(int q, int n_tiles, int num_groups) {
-  Wino4Work o;
+// Round 5: an XCD owns a CONTIGUOUS range of groups (group = xcd * ceil(num_groups / 8) + r / n_tiles) instead of every
+// eighth one: vertically adjacent tile rows share two of their six patch rows, and with the groups dealt round-robin
+// over the XCDs every XCD fetched its own copy of them from HBM (the 2.2x algorithmic bytes of round 4's PMC pass).
+// `xranges` = 0 restores the round-robin order (the launcher: PA_XCD_RANGES, and the 256-channel layers, where the
+// ranges measured 4 % slower without a residual).
+__device__ __forceinline__ int wino4_group_of(int q, int n_tiles, int num_groups, int xranges) {
   const int xcd = q & 7, r = q >> 3;
-  const int grp = (r / n_tiles) * 8 + xcd;
+  return xranges ? xcd * ((num_groups + 7) >> 3) + r / n_tiles : (r / n_tiles) * 8 + xcd;
+}
+__device__ __forceinline__ Wino4Work wino4_decode(int q, int n_tiles, int num_groups, int xranges = 1) {
+  Wino4Work o;
+  const int r = q >> 3;
+  const int grp = wino4_group_of(q, n_tiles, num_groups, xranges);
   o.n0 = (r % n_tiles) * W_BN;
   o.valid = grp < num_groups;
   o.unit0 = 4 * (grp < num_groups ? grp : num_groups - 1);

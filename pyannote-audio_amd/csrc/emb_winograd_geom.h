@@ -94,11 +94,14 @@ __device__ __forceinline__ void wino_patch_bases(int (&pbase)[8], int t, int g, 
 // the patch comes from HBM once instead of n_tiles times.  (pixel tile, image) = (r / n_tiles) * 8 + xcd;
 // the index space is padded to a multiple of 8 (pixel tile, image) pairs: padding tiles are computed on
 // the last real tile's data and not stored (valid = 0).
+// `xranges` (round 5): an XCD owns a CONTIGUOUS range of (pixel tile, image) pairs, pb = xcd * ceil(num_pb / 8) +
+// r / n_tiles, instead of every eighth one: neighbouring tiles share their halo rows / columns, and dealt round-robin
+// every XCD fetched its own copy of them from HBM.
 __device__ __forceinline__ WinoTile wino_decode(int q, int tiles_w, int tiles_hw, int n_tiles, int th,
-                                                int tw, int num_pb, int y_first = 0) {
+                                                int tw, int num_pb, int y_first = 0, int xranges = 0) {
   WinoTile o;
   const int xcd = q & 7, r = q >> 3;
-  int pb = (r / n_tiles) * 8 + xcd;
+  int pb = xranges ? xcd * ((num_pb + 7) >> 3) + r / n_tiles : (r / n_tiles) * 8 + xcd;
   o.n0 = (r % n_tiles) * W_BN;
   o.valid = pb < num_pb;
   pb = pb < num_pb ? pb : num_pb - 1;

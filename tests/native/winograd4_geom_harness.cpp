@@ -123,7 +123,9 @@ static int check_order(int B, int H, int W, int n_tiles) {
   for (int q = 0; q < total; ++q) {
     const Wino4Work w = wino4_decode(q, n_tiles, num_groups);
     if (w.n0 % W_BN || w.n0 / W_BN >= n_tiles || w.unit0 % 4 || w.unit0 / 4 >= num_groups) return printf("decode out of range\n"), 1;
-    if (w.valid && ((w.unit0 / 4) & 7) != (q & 7)) return printf("group %d is not on XCD %d\n", w.unit0 / 4, q & 7), 1;
+    // an XCD owns a contiguous range of groups (xranges = 1, the default); the cout slices of a group are consecutive claims
+    if (w.valid && (w.unit0 / 4) / ((num_groups + 7) / 8) != (q & 7)) return printf("group %d is not on XCD %d\n", w.unit0 / 4, q & 7), 1;
+    if (w.valid && w.n0 / W_BN != (q >> 3) % n_tiles) return printf("cout slices of a group are not consecutive claims\n"), 1;
     for (int s = 0; s < 4; ++s) {
       Wino4Unit u = wino4_unit(w.unit0 + s, cgroups, trows, num_units);
       u.valid &= w.valid;
