@@ -171,6 +171,16 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 #ifndef PA_W4_DEFER_STORES   // stores of channel group 0 issued from inside the column arithmetic of group 1:
 #define PA_W4_DEFER_STORES 1 // 0 = never, 1 = instantiation without residual only, 2 = both (spills: slower)
 #endif
+// cache-policy bits of the output stores / the residual loads (gfx942+: 1 = sc0, 2 = nt, 16 = sc1).  The outputs are
+// written once and read by the NEXT kernel, 9 GB later: non-temporal stores leave the L2 to the patches, whose lines are
+// touched by four consecutive stages (8 of a pixel's 32 channels each): -2 % per launch on average, -4 % at 256 channels
+// (profiles/r5_xcd_ranges.txt, section 4).  Non-temporal residual loads measured slower.
+#ifndef PA_W4_STORE_AUX
+#define PA_W4_STORE_AUX 2
+#endif
+#ifndef PA_W4_RES_AUX
+#define PA_W4_RES_AUX 0
+#endif
 #ifndef PA_W4_LATE_BARRIER   // the stage barrier behind most of the input transform (0: in front of it, as in round 4)
 #define PA_W4_LATE_BARRIER 1
 #endif
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       f32x4 held[4][4];
       auto store_held = [&](const int k) {   // (k: compile-time after unrolling)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, held[k >> 2][k & 3]), ysrd,
-                                               ooff(k >> 2, k & 3, 0), 0, 0);
+                                               ooff(k >> 2, k & 3, 0), 0, PA_W4_STORE_AUX);
       };
 #pragma unroll
       for (int cg = 0; cg < 2; ++cg) {
@@ -677,7 +687,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
               rv[p][qq] = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, ooff(p, qq, cg), 0, 0));
+                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, ooff(p, qq, cg), 0, PA_W4_RES_AUX));
         }
         __builtin_amdgcn_sched_barrier(0);
         f32x4 o[4][4];
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
               for (int qq = 0; qq < 4; ++qq)
                 rv[p][qq] = __builtin_bit_cast(
-                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, ooff(p, qq, cg), 0, 0));
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrd, ooff(p, qq, cg), 0, PA_W4_RES_AUX));
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -767,7 +777,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd, ooff(p, qq, cg), 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[p][qq]), ysrd, ooff(p, qq, cg), 0,
+                                                     PA_W4_STORE_AUX);
         }
         __builtin_amdgcn_sched_barrier(0);
 #if PA_W4_STAMP
