@@ -10,6 +10,9 @@
 //                  pixels x BN output channels; per 16-channel input block the (halo'd) input patch
 //                  and the 9 x BN x 16 weight slab are staged in LDS once and reused by all 9 taps.
 #include "common.h"
+#ifndef PA_CONV_STORE_AUX   // cache-policy bits of the output stores (2 = nt): A/B aid, see profiles/r5_xcd_ranges.txt
+#define PA_CONV_STORE_AUX 0
+#endif
 
 namespace pa {
 
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(const float* __restrict__ X,
           float v = acc[i][j][r] + sh + rv[g & 1][r];
           if (relu) v = fmaxf(v, 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ysrd,
-                                                off[g & 1][r], 0, 0);
+                                                off[g & 1][r], 0, PA_CONV_STORE_AUX);
         }
       }
     }

@@ -49,6 +49,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#ifndef PA_WINO_STORE_AUX   // cache-policy bits of the output stores (2 = nt): A/B aid, see profiles/r5_xcd_ranges.txt
+#define PA_WINO_STORE_AUX 0
+#endif
 
 #ifdef PA_WINO_NOSCHED   // development A/B switch (never defined in the product build)
 #define WINO_SCHED_BARRIER()
@@ -344,7 +347,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const f32x4 vv = __builtin_elementwise_max(o4[e] + sh + rv[cg][e], lo4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), ysrd, off[e] + 64 * cg, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), ysrd, off[e] + 64 * cg, 0, PA_WINO_STORE_AUX);
     }
   }
 }

@@ -13,6 +13,8 @@ VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or
     "conv_prev": ("emb_resnet.hip", "", "b01ddc8"),   # k_conv3x3 with the staging offsets recomputed every stage
     "w4tstores": ("emb_winograd4.hip", "-DPA_W4_STORE_AUX=0", None),        # F(4x4): output stores with the default (temporal) policy
     "w4ntr": ("emb_winograd4.hip", "-DPA_W4_RES_AUX=2", None),              # F(4x4): residual loads non-temporal
+    "winonty": ("emb_winograd.hip", "-DPA_WINO_STORE_AUX=2", None),         # F(2x2) kernels: output stores non-temporal
+    "convnty": ("emb_resnet.hip", "-DPA_CONV_STORE_AUX=2", None),           # direct kernel: output stores non-temporal
     "w4earlybar": ("emb_winograd4.hip", "-DPA_W4_LATE_BARRIER=0", None),   # F(4x4): stage barrier in front of the transform (round 4)
     "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
     "w4s_notransform": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOTRANSFORM=1", None),
