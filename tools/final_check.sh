@@ -8,7 +8,7 @@ tag=${1:-r3}
 O=gpurun_out/final_$tag; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1
 tail -4 $O/gpu_tests.txt
-timeout 200 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 tail -2 $O/smoke.txt
 timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 \
