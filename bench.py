@@ -184,7 +184,8 @@ def load_traffic(kernel: str):
     WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; summarised by
     tools/pmc_traffic.py).  PMC counters cannot be read from inside this process, so the figure is a
     STATIC one and says which file / commit it comes from."""
-    for name in ("r4_traffic.json", "r3_traffic.json", "r3a_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r3a_traffic.json", "r2_traffic.json",
+                 "r1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fp:
                 d = json.load(fp)

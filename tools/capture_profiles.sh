@@ -6,6 +6,9 @@ tag=${1:-r2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+# (PA_WINOGRAD_GUARD=0: the load-time guard of EmbeddingPack launches every convolution kernel once on two 3-s chunks --
+#  ~80 tiny launches that would dilute the per-launch averages of the kernels measured here)
+export PA_WINOGRAD_GUARD=0
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --sequential"
 python tools/probes/pingpong_probe.py > $out/mfma_probe.txt 2>&1
 python tools/clock_trace.py > $out/clock_trace.txt 2>&1
