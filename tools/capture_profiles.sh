@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 #  ~80 tiny launches that would dilute the per-launch averages of the kernels measured here)
 export PA_WINOGRAD_GUARD=0
 CMD="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --sequential"
+sh tools/probes/build.sh > $out/probes_build.log 2>&1   # (tools/_dbg is git-ignored: build here if the caller did not)
 python tools/probes/pingpong_probe.py > $out/mfma_probe.txt 2>&1
 python tools/clock_trace.py > $out/clock_trace.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/bench_under_rocprof.json 2> $out/stats.err
