@@ -49,6 +49,12 @@
 #include <stdlib.h>
 
 #include "common.h"
+#ifndef PA_WINO32_PATCH_FIRST   // k_conv3x3_wino32: the next tile's patch DMA in front of the epilogue (0: behind it, round 3)
+#define PA_WINO32_PATCH_FIRST 1
+#endif
+#ifndef PA_WINO32_WAIT_STORES   // 1: the step barrier of k_conv3x3_wino32 also waits for the epilogue's stores (A/B aid)
+#define PA_WINO32_WAIT_STORES 0
+#endif
 #ifndef PA_WINO_STORE_AUX   // cache-policy bits of the output stores (2 = nt): A/B aid, see profiles/r5_xcd_ranges.txt
 #define PA_WINO_STORE_AUX 0
 #endif
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino32(
   // step s: half h COMPUTES when (s - h) is even and >= 0, otherwise it PREPARES
   for (int step = 0;; ++step) {
     const bool compute = step >= half && ((step - half) & 1) == 0;
+    bool stored = false;        // this step ended with the stores of an epilogue (wave-uniform)
     if (compute) {
       if (q >= 0) {
         if (leader) mail[half] = tq_resolve(tq, ahead);   // the claim was issued a step ago: no round trip here
@@ -621,6 +628,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino32(
     } else if (step >= half) {
       // PREPARE: epilogue of the tile computed in the previous step, then the patch of the next one
       const int qn = done_q >= 0 ? mail[half] : -1;   // (published by the barrier that closed the COMPUTE step)
+#if PA_WINO32_PATCH_FIRST
+      // the next tile's patch goes out FIRST (its buffers are free: this half's COMPUTE step has read them), so that its
+      // flight overlaps the epilogue instead of following it: the layer is at 60-65 % of both of its bounds for lack of
+      // loads in flight (profiles/r5_hbm_bw.txt)
+      q = qn;
+      if (q >= 0) {
+        cur = wino_decode(q, tiles_w, tiles_hw, 1, 8, 32, num_pb, 0, xranges);
+        wino_issue_patch<4, 1>(X, H, W, CIN, cur, 0, patch, prel, slw, x0_last);
+        wino_issue_patch<4, 1>(X, H, W, CIN, cur, WCB, patch + G::PATCH, prel, slw, x0_last);
+        if (leader) ahead = tq_claim_own(tq);
+      }
+      if (done_q >= 0) {
+        wino_epilogue<HAS_R>(acc, fin, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1);
+        done_q = -1;
+        stored = true;
+      }
+#else
       if (done_q >= 0) {
         wino_epilogue<HAS_R>(acc, fin, H, W, COUT, shift, R, Y, relu, t, g, wr, wc, m1);
         done_q = -1;
@@ -632,8 +656,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino32(
         wino_issue_patch<4, 1>(X, H, W, CIN, cur, WCB, patch + G::PATCH, prel, slw, x0_last);
         if (leader) ahead = tq_claim_own(tq);
       }
+#endif
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // what the barrier needs is this half's patch in LDS.  The epilogue's 8 stores per lane are the NEWEST vector memory
+    // operations of a PREPARE step (the patch pieces and the residual loads are older) and complete in order: leaving
+    // them in flight across the barrier takes their acknowledgement latency off every step's critical path.
+    if (PA_WINO32_PATCH_FIRST && !PA_WINO32_WAIT_STORES && stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wino_barrier();
     if (mail[2] == 0 && mail[3] == 0) break;
   }

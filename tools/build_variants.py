@@ -13,6 +13,8 @@ VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or
     "conv_prev": ("emb_resnet.hip", "", "b01ddc8"),   # k_conv3x3 with the staging offsets recomputed every stage
     "w4tstores": ("emb_winograd4.hip", "-DPA_W4_STORE_AUX=0", None),        # F(4x4): output stores with the default (temporal) policy
     "w4ntr": ("emb_winograd4.hip", "-DPA_W4_RES_AUX=2", None),              # F(4x4): residual loads non-temporal
+    "w32waitstores": ("emb_winograd.hip", "-DPA_WINO32_WAIT_STORES=1", None),   # k_conv3x3_wino32: the step barrier waits for the epilogue's stores too
+    "w32patchlast": ("emb_winograd.hip", "-DPA_WINO32_PATCH_FIRST=0", None),   # k_conv3x3_wino32: patch DMA behind the epilogue (round 3)
     "winonty": ("emb_winograd.hip", "-DPA_WINO_STORE_AUX=2", None),         # F(2x2) kernels: output stores non-temporal
     "convnty": ("emb_resnet.hip", "-DPA_CONV_STORE_AUX=2", None),           # direct kernel: output stores non-temporal
     "w4earlybar": ("emb_winograd4.hip", "-DPA_W4_LATE_BARRIER=0", None),   # F(4x4): stage barrier in front of the transform (round 4)
