@@ -181,6 +181,9 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 #ifndef PA_W4_RES_AUX
 #define PA_W4_RES_AUX 0
 #endif
+#ifndef PA_W4_STORES_IN_FLIGHT   // a tile's first stage does not wait for the previous tile's stores (0: vmcnt(0) as in round 4)
+#define PA_W4_STORES_IN_FLIGHT 1
+#endif
 #ifndef PA_W4_LATE_BARRIER   // the stage barrier behind most of the input transform (0: in front of it, as in round 4)
 #define PA_W4_LATE_BARRIER 1
 #endif
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   int claim = 0;
   if (tid == 0) claim = tq_claim_own(tq);
   int nq = -1;
+  bool first_tile = true;
   f32x4 acca[W4_AGPR_POINTS][2];        // points 0 .. 31: AccVGPRs
   f32x4 accv[36 - W4_AGPR_POINTS][2];   // points 32 .. 35: architectural registers
 
@@ -390,8 +394,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // tile's first stage still waits for everything here: the epilogue's stores and residual loads were issued
       // behind its staging.  (PA_W4_LATE_BARRIER=0: round 4's order, barrier in front of the transform.)
 #if PA_W4_LATE_BARRIER
-      if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      if (s == 0) {
+        // A tile's first stage: its staging was issued from inside the PREVIOUS tile's last MFMA run, i.e. in front of
+        // that tile's epilogue, whose last 32 vector memory operations per lane are 32 stores (without a residual) or
+        // the 16 residual loads + 16 stores of channel group 1 (with one) -- all newer than the staging, and memory
+        // operations complete in order: vmcnt(32) = "the staging has landed" without waiting for the acknowledgement of
+        // the stores (~2 k cycles per tile).  (The next group's claim -- an atomic of thread 0 -- is issued in FRONT of
+        // the epilogue for that reason.)  The first tile of a workgroup has nothing but its staging in flight.
+        if (PA_W4_STORES_IN_FLIGHT && !first_tile) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      }
 #else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
 #endif
@@ -610,6 +624,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         W4_STAMP_FLUSH();
       }
     }
+    // (the claim of the group after the next one: an atomic -- in front of the epilogue's stores, see the first-stage wait)
+    if (tid == 0 && nq >= 0) claim = tq_claim_own(tq);
+    first_tile = false;
     // ---- inverse transform A^T M A + BN shift (+ residual) (+ ReLU), 16-byte stores
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results (the compiler cannot see them)
     {
@@ -797,7 +814,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     }
     cur_n0 = nxt_n0;
     cctx = nctx;
-    if (tid == 0) claim = tq_claim_own(tq);
   }
   if (tid == 0) tq_done(tq, gridDim.x);
 }

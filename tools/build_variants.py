@@ -17,6 +17,7 @@ VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or
     "w32patchlast": ("emb_winograd.hip", "-DPA_WINO32_PATCH_FIRST=0", None),   # k_conv3x3_wino32: patch DMA behind the epilogue (round 3)
     "winonty": ("emb_winograd.hip", "-DPA_WINO_STORE_AUX=2", None),         # F(2x2) kernels: output stores non-temporal
     "convnty": ("emb_resnet.hip", "-DPA_CONV_STORE_AUX=2", None),           # direct kernel: output stores non-temporal
+    "w4waitstores": ("emb_winograd4.hip", "-DPA_W4_STORES_IN_FLIGHT=0", None),   # F(4x4): a tile's first stage waits for the previous tile's stores
     "w4earlybar": ("emb_winograd4.hip", "-DPA_W4_LATE_BARRIER=0", None),   # F(4x4): stage barrier in front of the transform (round 4)
     "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
     "w4s_notransform": ("emb_winograd4.hip", "-DPA_W4_STAMP=1 -DPA_W4_NOTRANSFORM=1", None),
