@@ -25,6 +25,7 @@ for f in ("bench_default.json", "bench_torchrun_n1.json", "bench_sequential.json
         print(f, "ERR", e)
 PY
 ls gpurun_out/prof_$tag
+[ -n "$SKIP_LINKAGE" ] && exit 0
 # configs[4] on one GPU (joint clustering over 1..8 one-hour files) and the dendrogram merge alone
 timeout 400 python tools/joint_scale.py 1 2 4 8 > $O/joint_scale.txt 2>&1; tail -12 $O/joint_scale.txt
 timeout 200 python tools/time_linkage.py 7000 14000 29000 57000 > $O/time_linkage.txt 2>&1; tail -8 $O/time_linkage.txt
