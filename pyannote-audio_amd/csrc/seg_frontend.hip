@@ -66,21 +66,23 @@ constexpr int SINC_T = 640;                        // threads
 // RAW = true (the sinc layer ONCE for a whole span of overlapping chunks, see k_sinc_fix_pool): no normalisation on
 // load, no magnitude, no pooling -- MFMA row i is convolution position i, `P` counts convolution positions and `out`
 // is (80, P) raw filter outputs of the span [wav, wav + N).
-template <bool RAW>
+// STR: the SincNet stride (models/blocks/sincnet.py:58-69 accepts any; the released checkpoints use 10).  The staged
+// sample window of a workgroup is 3 STR SINC_PT + 256 floats (30 KB at STR = 20).
+template <bool RAW, int STR = 10>
 __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
     const float* __restrict__ wav, long wav_len, long chunk_stride, int N, int stride, int P,
     const float* __restrict__ mean, const float* __restrict__ rstd, float gamma, float beta,
     const float* __restrict__ filt, float* __restrict__ out) {
+  constexpr int XS_MAX = 3 * STR * SINC_PT + 256;   // (= SINC_XS at STR = 10)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                // [SINC_XS]
-  float* os = smem + SINC_XS;      // [80][SINC_OS]
+  float* xs = smem;                // [XS_MAX]
+  float* os = smem + XS_MAX;       // [80][SINC_OS]
   const int b = blockIdx.y;
   const int p0 = blockIdx.x * SINC_PT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = (tid >> 6) % 5, half = (tid >> 6) / 5;   // filter tile, half of the positions
-  constexpr int STR = 10;                   // SincNet stride (checked by the host wrapper)
   constexpr int PS = RAW ? STR : 3 * STR;   // sample advance per output row (pooled: three positions per row)
-  constexpr int XS = RAW ? STR * SINC_PT + 256 : SINC_XS;   // staged samples
+  constexpr int XS = RAW ? STR * SINC_PT + 256 : XS_MAX;    // staged samples
 
   // stage normalised samples [PS*p0, PS*p0 + nstage)
   const long cbase = (long)b * chunk_stride;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(SINC_T) void k_sinc_fir_pool(
   // (all loads of a thread are issued before the first use: as a plain loop the compiler waits for every load
   //  in turn)
   {
-    constexpr int NS = (SINC_XS + SINC_T - 1) / SINC_T;
+    constexpr int NS = (XS_MAX + SINC_T - 1) / SINC_T;
     float raw[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -320,19 +322,36 @@ int pa_row_stats(const float* x, long row_stride, long total_len, int rows, int 
 int pa_sinc_fir_pool(const float* wav, long wav_len, long chunk_stride, int B, int N, int stride,
                      const float* mean, const float* rstd, float gamma, float beta,
                      const float* filt_packed, float* out, void* stream) {
-  PA_REQUIRE(stride == 10, "pa_sinc_fir_pool: only SincNet stride 10 is built (got %d)", stride);
+  PA_REQUIRE(stride >= 1 && N >= 251, "pa_sinc_fir_pool: stride %d / %d samples", stride, N);
   const int L = (N - 251) / stride + 1;
   const int P = L / 3;
   if (B <= 0 || P <= 0) return 0;
-  const size_t lds = (pa::SINC_XS + 80 * pa::SINC_OS) * sizeof(float);
-  // (set on every call: the attribute belongs to the current device, not to the process)
-  (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
   pa::ProfScope prof("k_sinc_fir_pool", stream, 2.0 * B * 80 * 251 * (3.0 * P),
                      4.0 * B * N + 4.0 * B * 80 * P);
-  hipLaunchKernelGGL(pa::k_sinc_fir_pool<false>, dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(pa::SINC_T), lds,
-                     (hipStream_t)stream, wav, wav_len, chunk_stride, N, stride, P, mean, rstd, gamma,
-                     beta, filt_packed, out);
+#define PA_SINC_LAUNCH(S)                                                                                          \
+  do {                                                                                                             \
+    const size_t lds = (size_t)(3 * (S) * pa::SINC_PT + 256 + 80 * pa::SINC_OS) * sizeof(float);                     \
+    /* (set on every call: the attribute belongs to the current device, not to the process) */                     \
+    (void)hipFuncSetAttribute((const void*)pa::k_sinc_fir_pool<false, S>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                           \
+    hipLaunchKernelGGL((pa::k_sinc_fir_pool<false, S>), dim3(pa::cdiv(P, pa::SINC_PT), B), dim3(pa::SINC_T), lds,  \
+                       (hipStream_t)stream, wav, wav_len, chunk_stride, N, stride, P, mean, rstd, gamma, beta,      \
+                       filt_packed, out);                                                                          \
+  } while (0)
+  // the strides that are built (the kernel's staging window and MFMA row pitch are compile-time)
+  switch (stride) {
+    case 10: PA_SINC_LAUNCH(10); break;
+    case 1: PA_SINC_LAUNCH(1); break;
+    case 2: PA_SINC_LAUNCH(2); break;
+    case 4: PA_SINC_LAUNCH(4); break;
+    case 5: PA_SINC_LAUNCH(5); break;
+    case 8: PA_SINC_LAUNCH(8); break;
+    case 16: PA_SINC_LAUNCH(16); break;
+    case 20: PA_SINC_LAUNCH(20); break;
+    default:
+      PA_REQUIRE(false, "pa_sinc_fir_pool: SincNet stride %d is not built (1, 2, 4, 5, 8, 10, 16, 20 are)", stride);
+  }
+#undef PA_SINC_LAUNCH
   PA_CHECK_LAUNCH("pa_sinc_fir_pool");
   return 0;
 }

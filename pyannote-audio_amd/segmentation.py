@@ -76,7 +76,7 @@ class SegmentationEngine:
 
     # -- model-specific entry points (PyanNet here; SSeRiouSSEngine overrides them)
     def frames_of(self, num_samples: int) -> int:
-        return num_frames(num_samples)
+        return num_frames(num_samples, int(self.pack.struct.sinc_stride) or 10)
 
     def _workspace_bytes(self, lib, w, nb, num_samples, chunk_stride):
         return lib.pa_seg_workspace_bytes_strided(w, nb, num_samples, chunk_stride)

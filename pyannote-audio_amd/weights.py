@@ -105,8 +105,8 @@ class SegmentationPack:
         lstm = {"hidden_size": 128, "num_layers": 2, "bidirectional": True, "monolithic": True,
                 **(hparams.get("lstm") or {})}
         linear = {"hidden_size": 128, "num_layers": 2, **(hparams.get("linear") or {})}
-        if sinc["stride"] != 10:
-            raise NotImplementedError("kernels are built for SincNet stride 10")
+        if int(sinc["stride"]) not in SINC_STRIDES:
+            raise NotImplementedError(f"SincNet stride {sinc['stride']}: the kernel is built for {SINC_STRIDES}")
         H, ndir, lw = lstm_geometry(lstm, linear)
         self.device = device
         self._keep: list[torch.Tensor] = []
@@ -116,6 +116,7 @@ class SegmentationPack:
         w.num_linear, w.linear_hidden = int(linear["num_layers"]), lw
         w.num_classes, w.num_speakers = num_classes, num_speakers
         self.sinc_taps = pack_sincnet(sd, w, self._up)  # (80, 251) kept for tests
+        w.sinc_stride = int(sinc["stride"])
 
         pack_lstm_head(sd, w, lstm, self._up)
         # max_set_size None / 0 = a multi-label (non-powerset) checkpoint: sigmoid scores, no look-up table
@@ -202,6 +203,11 @@ def pack_lstm_head(sd: dict, w, lstm: dict, up):
         w.lin_b[l] = up(sd[f"linear.{l}.bias"]).value
     w.cls_w = up(sd["classifier.weight"])
     w.cls_b = up(sd["classifier.bias"])
+
+
+#: SincNet strides k_sinc_fir_pool is instantiated for (csrc/seg_frontend.hip; sincnet.py:58-69 accepts any, the
+#: released checkpoints use 10 -- only that one takes the shared per-span sinc layer)
+SINC_STRIDES = (1, 2, 4, 5, 8, 10, 16, 20)
 
 
 def pack_sincnet(sd: dict, w, up) -> torch.Tensor:

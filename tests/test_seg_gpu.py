@@ -295,3 +295,28 @@ def test_lstm_recurrence_any_width_through_the_c_abi(gpu_device):
         torch.cuda.synchronize()
         got = out.view(ntiles, T, 16, ndir * H).permute(0, 2, 1, 3).reshape(ntiles * 16, T, ndir * H)[:B].cpu()
         assert north_star_ratio(f"lstm_rec_h_H{H}_d{ndir}", got, ref) <= 1.0
+
+
+@pytest.mark.parametrize("stride", [5, 16])
+def test_other_sincnet_strides_match_oracle(gpu_device, stride):
+    """SincNet(stride=...) (models/blocks/sincnet.py:58-69; PyanNet hyper-parameter `sincnet.stride`): the sinc kernel is
+    instantiated per stride (the per-chunk form; the shared per-span sinc layer stays with stride 10) -- log-probs against
+    the oracle, frame counts from the same geometry."""
+    from oracle.models import PyanNet
+    from pyannote_audio_amd.weights import SegmentationPack
+    from pyannote_audio_amd.segmentation import SegmentationEngine
+    torch.manual_seed(5)
+    hp = {"sincnet": {"stride": stride}, "lstm": {"hidden_size": 128, "num_layers": 2}}
+    model = PyanNet(num_classes=7, sincnet=hp["sincnet"], lstm=hp["lstm"]).eval()
+    pack = SegmentationPack(model.state_dict(), hp, 7, 3, 2, gpu_device)
+    assert pack.struct.sinc_stride == stride
+    eng = SegmentationEngine(pack)
+    B, N, step = 19, 48000, 6000
+    wav = _wave(1, step * (B - 1) + N, seed=23).view(-1)
+    chunks = torch.stack([wav[b * step: b * step + N] for b in range(B)]).unsqueeze(1)
+    with torch.inference_mode():
+        ref = model(chunks)
+    logp, ml = eng.forward_strided(wav.to(gpu_device), step, B, N)
+    torch.cuda.synchronize()
+    assert logp.shape == ref.shape == (B, model.num_frames(N), 7)
+    assert north_star_ratio(f"seg_sinc_stride_{stride}", logp, ref) <= 1.0
