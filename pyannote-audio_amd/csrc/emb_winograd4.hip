@@ -292,6 +292,20 @@ __device__ __forceinline__ Wino4LinUnit wino4_lin_unit(int u, int tcols, int tro
   for (int i = 0; i < Wino4LinGeom::PINSTR; ++i) off[i] = wino4_lin_patch_lane(i, td, H, W, CIN, lane);
   return o;
 }
+// the same for a RUN-shaped unit (emb_winograd4_geom.h): 15 lane offsets, the lane's tile and its patch slot
+__device__ __forceinline__ Wino4LinUnit wino4_run_unit(int u, int tcols, int trows, int total_tiles, int H, int W,
+                                                       int CIN, int nimg, int lane, int (&off)[Wino4RunGeom::PINSTR],
+                                                       int* slot) {
+  Wino4LinUnit o;
+  int b0;
+  const Wino4Runs R = wino4_runs(u, tcols, trows, &b0);
+  o.b0 = __builtin_amdgcn_readfirstlane(b0);
+  const int t = lane & 15;
+  o.tc = wino4_run_tile(R, t, u, total_tiles);
+  *slot = t + wino4_run_of_tile(R, t);
+  wino4_run_patch_lanes(off, R, H, W, CIN, nimg - o.b0, lane);
+  return o;
+}
 // staging context of a tile-linear unit: the descriptor starts at the unit's first image and runs to the end of the
 // tensor (clamped to 2^31 - 1); every halo is an out-of-bounds lane offset, `keep` passes everything through
 __device__ __forceinline__ Wino4Ctx wino4_lin_ctx(const float* __restrict__ X, int H, int W, int CIN, int nimg, int b0,
@@ -309,13 +323,20 @@ __device__ __forceinline__ Wino4Ctx wino4_lin_ctx(const float* __restrict__ X, i
 
 // LIN: tile-linear units (16 consecutive tiles of the raster order; `cgroups` = tile columns, `num_units` = total
 // tiles, `nimg` = images) instead of row-shaped ones -- see emb_winograd4_geom.h and launch_wino4.
-template <bool HAS_R, bool LIN>
+// MODE: 0 row-shaped units, 1 tile-linear units with tile-private patches, 2 tile-linear units in RUN shape
+template <bool HAS_R, int MODE>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     const float* __restrict__ X, int H, int W, int CIN, const float* __restrict__ U,
     const float* __restrict__ shift, const float* __restrict__ R, float* __restrict__ Y, int COUT, int relu,
     int cgroups, int trows, int num_units, int num_groups, int n_tiles, int total_work, int nimg, int xranges,
     int* __restrict__ counters) {
-  using G = std::conditional_t<LIN, Wino4LinGeom, Wino4Geom>;
+  // the late stage barrier pays for the row-shaped units only (-0.8 %; the linear forms: +0.4 .. +1.3 %), and with the
+  // barrier in FRONT of the transform the linear forms learn their next unit early enough to compute its lane offsets
+  // before the transform's 144 live registers exist
+  constexpr bool LATE = PA_W4_LATE_BARRIER && MODE == 0;
+  constexpr bool LIN = MODE != 0;    // a unit = 16 consecutive tiles of the raster order (per-lane tiles)
+  constexpr bool RUN = MODE == 2;    // ... whose patch keeps the row-shaped layout, run by run
+  using G = std::conditional_t<MODE == 0, Wino4Geom, std::conditional_t<MODE == 1, Wino4LinGeom, Wino4RunGeom>>;
   constexpr int PIN = G::PINSTR;
   constexpr int W4_PIECES = PIN + 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
@@ -338,8 +359,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   Wino4Lanes<PIN> pl;      // row-shaped units: per kernel; tile-linear: the CURRENT unit's lane offsets
   Wino4Lanes<PIN> npl;     // tile-linear: the next unit's (computed in the current tile's last stage)
   if constexpr (!LIN) wino4_patch_lanes(pl.a, W, CIN, lane, x0_last);
-  const int pbase0 = LIN ? wino4_lin_patch_base(t, g) : wino4_patch_base(t, g, 0);
-  const int pbase1 = LIN ? pbase0 : wino4_patch_base(t, g, 1);
+#define W4_PATCH_K(i, j) (MODE == 1 ? wino4_lin_patch_k(i, j) : (MODE == 2 ? wino4_run_patch_k(i, j) : wino4_patch_k(i, j)))
+  // transform read bases of this lane (run-shaped units: of its slot in the CURRENT unit, refreshed per unit)
+  int pbase0 = MODE == 1 ? wino4_lin_patch_base(t, g) : wino4_patch_base(t, g, 0);
+  int pbase1 = MODE == 1 ? pbase0 : wino4_patch_base(t, g, 1);
+  int nxt_slot = 0;
+  // (tile-linear: the kernel's `num_units` argument carries the number of TILES)
+  const int last_unit = LIN ? ((num_units + 15) >> 4) - 1 : 0;
   const int ubase = wino4_u_base(t, g);
   const int lane16 = lane * 16;
   W4Const kc;
@@ -358,7 +384,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   Wino4LinUnit lcur = Wino4LinUnit{0, Wino4LinTile{0, 0, 0, 0}}, lnxt = lcur;
   int cur_n0 = wk.n0, nxt_n0 = wk.n0;
   Wino4Ctx cctx;
-  if constexpr (LIN) {
+  if constexpr (RUN) {
+    const int uu = wk.unit0 + slw;
+    int slot;
+    lcur = wino4_run_unit(uu < last_unit ? uu : last_unit, cgroups, trows, num_units, H, W, CIN, nimg, lane, pl.a, &slot);
+    lcur.tc.valid &= wk.valid & (uu <= last_unit);
+    pbase0 = wino4_run_patch_base(slot, g, 0);
+    pbase1 = wino4_run_patch_base(slot, g, 1);
+    cctx = wino4_lin_ctx(X, H, W, CIN, nimg, lcur.b0, cur_n0);
+  } else if constexpr (LIN) {
     lcur = wino4_lin_unit(wk.unit0 + slw, cgroups, trows, num_units, H, W, CIN, lane, pl.a);
     lcur.tc.valid &= wk.valid;
     cctx = wino4_lin_ctx(X, H, W, CIN, nimg, lcur.b0, cur_n0);
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // transform's column pass and first rows, which hide what is left of the U flight and of the waves' skew.  A
       // tile's first stage still waits for everything here: the epilogue's stores and residual loads were issued
       // behind its staging.  (PA_W4_LATE_BARRIER=0: round 4's order, barrier in front of the transform.)
-#if PA_W4_LATE_BARRIER
+      if constexpr (LATE) {
       if (s == 0) {
         // A tile's first stage: its staging was issued from inside the PREVIOUS tile's last MFMA run, i.e. in front of
         // that tile's epilogue, whose last 32 vector memory operations per lane are 32 stores (without a residual) or
@@ -406,9 +440,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       } else {
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       }
-#else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
-#endif
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)
+      }
       W4_STAMP(1);
       // the claim of the NEXT group was issued at the start of this tile: its value is picked up here, behind the
       // wait above (anywhere else the compiler's own vmcnt wait for it would also wait for staging in flight), and
@@ -421,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #if !defined(PA_W4_NOPATCHREAD) && !defined(PA_W4_NOTRANSFORM)
 #pragma unroll
       for (int i = 0; i < 6; ++i)
-        x_first[i] = w4_lds_read64(my_patch + pbase0 + (LIN ? wino4_lin_patch_k(i, 0) : wino4_patch_k(i, 0)));
+        x_first[i] = w4_lds_read64(my_patch + pbase0 + W4_PATCH_K(i, 0));
 #endif
       unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
       unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
@@ -430,9 +464,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       Wino4Stage nst;
       // the stage barrier + everything that needs it (the mailbox of the tile's last stage)
       auto stage_barrier = [&]() {
-#if PA_W4_LATE_BARRIER
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's U pieces
-#endif
+        if constexpr (LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's U pieces
         __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done with the other buffer
         asm volatile("" ::: "memory");
         W4_STAMP(2);
@@ -444,8 +476,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           wk = wino4_decode(stage_next ? nq : 0, n_tiles, num_groups, xranges);
           nxt_n0 = wk.n0;
           if constexpr (LIN) {
-            // (the next unit's 18 lane offsets are computed behind the transform, where the registers are free)
-            lnxt.b0 = __builtin_amdgcn_readfirstlane(wino4_lin_b0(wk.unit0 + slw, cgroups, trows, num_units));
+            // the next unit: its lane offsets and this lane's tile of it -- here, in front of the transform
+            const int uu = wk.unit0 + slw;
+            if constexpr (RUN) {
+              lnxt = wino4_run_unit(uu < last_unit ? uu : last_unit, cgroups, trows, num_units, H, W, CIN, nimg, lane,
+                                    npl.a, &nxt_slot);
+              lnxt.tc.valid &= wk.valid & (uu <= last_unit);
+            } else {
+              lnxt = wino4_lin_unit(uu, cgroups, trows, num_units, H, W, CIN, lane, npl.a);
+              lnxt.tc.valid &= wk.valid;
+            }
             nctx = wino4_lin_ctx(X, H, W, CIN, nimg, lnxt.b0, nxt_n0);
           } else {
             nxt = wino4_unit(wk.unit0 + slw, cgroups, trows, num_units);
@@ -455,16 +495,12 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           nst = wino4_stage(nctx, U, COUT, CIN, 0, my_patch, uother);
         }
       };
-#if !PA_W4_LATE_BARRIER
-      stage_barrier();
-#endif
+      if constexpr (!LATE) stage_barrier();
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
       f32x2 uf_first[2][2];   // (U fragments of the first point pair, read inside the transform)
 #ifdef PA_W4_NOTRANSFORM   // development A/B (timing only): no reads, no arithmetic
-#if PA_W4_LATE_BARRIER
-      stage_barrier();
-#endif
+      if constexpr (LATE) stage_barrier();
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #ifdef PA_W4_NOPATCHREAD   // development A/B (timing only): the arithmetic on register values, no LDS reads
 #define W4_RD(i, j) f32x2{(float)(lane + (i)), (float)(s + (j))}
 #else
-#define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + (LIN ? wino4_lin_patch_k(i, j) : wino4_patch_k(i, j)))
+#define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + W4_PATCH_K(i, j))
 #endif
 #pragma unroll
 #ifdef PA_W4_NOPATCHREAD
@@ -506,10 +542,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #pragma unroll
         for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
           if (i + W4_ROWS_PER_REGION >= 6) {
-#if PA_W4_LATE_BARRIER
-            stage_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            if constexpr (LATE) {
+              stage_barrier();
+              __builtin_amdgcn_sched_barrier(0);
+            }
             // the U fragments of the MFMA run's first point pair go out in front of the transform's last row(s):
             // their LDS latency no longer opens the run
 #pragma unroll
@@ -534,16 +570,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 #if PA_W4_ASM_DMA
       int plm[PIN];
       if constexpr (LIN) {
-        if (s + 1 < nstages) {
 #pragma unroll
-          for (int i = 0; i < PIN; ++i) plm[i] = pl.a[i];
-        } else {
-          // the next unit: its lane offsets (and this lane's tile of it)
-          lnxt = wino4_lin_unit(wk.unit0 + slw, cgroups, trows, num_units, H, W, CIN, lane, npl.a);
-          lnxt.tc.valid &= wk.valid;
-#pragma unroll
-          for (int i = 0; i < PIN; ++i) plm[i] = npl.a[i];
-        }
+        for (int i = 0; i < PIN; ++i) plm[i] = s + 1 < nstages ? pl.a[i] : npl.a[i];
       } else {
 #pragma unroll
         for (int i = 0; i < PIN; ++i) plm[i] = pl.a[i] & nst.keep;
@@ -811,6 +839,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
     if constexpr (LIN) {
       lcur = lnxt;
       pl = npl;
+      if constexpr (RUN) {
+        pbase0 = wino4_run_patch_base(nxt_slot, g, 0);
+        pbase1 = wino4_run_patch_base(nxt_slot, g, 1);
+      }
     }
     cur_n0 = nxt_n0;
     cctx = nctx;
@@ -822,13 +854,21 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
 // their tiles do not share halos: 18 instead of 13 patch pieces and 45 % more patch bytes per stage -- a unit costs
 // 1.14x (256 channels) to 1.24x (64 channels) as much (profiles/r5_wino4_linear_units.txt).  Linear when it has at least
 // 1.2x fewer units.  PA_WINO4_LINEAR=0 / 1 forces one of them (A/B aid).
-static bool wino4_linear_wanted(int B, int H, int W, int rows) {
-  if (rows != H) return false;                      // (row ranges: the row-shaped kernel)
-  static const char* e = getenv("PA_WINO4_LINEAR");
-  if (e != nullptr) return atoi(e) != 0;
+// -> 0 row-shaped, 1 tile-private, 2 run-shaped.  The run-shaped form keeps the shared halos of the row-shaped unit
+// (15 pieces, 1.1x its patch bytes: ~1.06x per unit) and is taken whenever it has at least 1.08x fewer units and the map
+// has at least 5 tiles per row (at most 4 runs per unit); the tile-private form serves narrower maps when it pays
+// (1.2x fewer units).  PA_WINO4_LINEAR=0 / 1 / 2 forces a form (A/B aid).
+static int wino4_unit_mode(int B, int H, int W, int rows) {
+  if (rows != H) return 0;                          // (row ranges: the row-shaped kernel)
   const long tcols = cdiv(W, 4), trows = cdiv(H, 4);
+  static const char* e = getenv("PA_WINO4_LINEAR");
+  if (e != nullptr) {
+    const int m = atoi(e);
+    return m == 2 && tcols < 5 ? 1 : m;
+  }
   const long lin_units = cdiv((long)B * trows * tcols, 16), row_units = (long)B * trows * cdiv(W, 64);
-  return lin_units * 120 <= row_units * 100;
+  if (tcols >= 5 && lin_units * 108 <= row_units * 100) return 2;
+  return lin_units * 120 <= row_units * 100 ? 1 : 0;
 }
 
 // tile order: contiguous ranges per XCD (neighbouring tiles share their halos in one L2) or round-robin;
@@ -838,15 +878,16 @@ int xcd_ranges_wanted(bool by_default) {
   return e != nullptr ? (atoi(e) != 0) : (by_default ? 1 : 0);
 }
 
-template <bool HAS_R, bool LIN>
+template <bool HAS_R, int MODE>
 static int launch_wino4(const float* X, int B, int H, int W, int CIN, const float* U, const float* shift,
                         const float* R, float* Y, int COUT, int relu, int rows, hipStream_t st) {
-  using G = std::conditional_t<LIN, Wino4LinGeom, Wino4Geom>;
+  constexpr bool LIN = MODE != 0;
+  using G = std::conditional_t<MODE == 0, Wino4Geom, std::conditional_t<MODE == 1, Wino4LinGeom, Wino4RunGeom>>;
   // row-shaped: column groups of 64 pixels x tile rows (rows < H: the tile rows that cover them only);
   // tile-linear: tile columns x tile rows, units of 16 consecutive tiles
   const int cgroups = LIN ? cdiv(W, 4) : cdiv(W, Wino4Geom::TW), trows = cdiv(rows, 4);
   const size_t lds = (size_t)G::LDS_BYTES + 16;
-  auto kernel = k_conv3x3_wino4<HAS_R, LIN>;
+  auto kernel = k_conv3x3_wino4<HAS_R, MODE>;
   constexpr int MAXDEV = 16;
   static int cus_of[MAXDEV] = {0};
   int dev = 0;
@@ -918,17 +959,22 @@ int pa_conv3x3_wino4_rows(const float* X, int B, int H, int W, int cin, const fl
                      4.0 * ((double)B * rows * W * cin + (double)B * rows * W * cout * (R ? 2 : 1) + 9.0 * cin * cout));
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (pa::wino4_linear_wanted(B, H, W, rows)) {
+  const int mode = pa::wino4_unit_mode(B, H, W, rows);
+  if (mode != 0) {
     // a unit may straddle images: its lane offsets count from the unit's first image
     const long per = (long)pa::cdiv(H, 4) * pa::cdiv(W, 4);
     const long span = (15 / per + 2) * (long)H * W * (cin > cout ? cin : cout) * 4;
     PA_REQUIRE(span < (1L << 31), "pa_conv3x3_wino4: the images a 16-tile unit can touch must stay below 2 GB");
-    rc = R != nullptr ? pa::launch_wino4<true, true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
-                      : pa::launch_wino4<false, true>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
-  } else {
-    rc = R != nullptr ? pa::launch_wino4<true, false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
-                      : pa::launch_wino4<false, false>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
   }
+  if (mode == 2)
+    rc = R != nullptr ? pa::launch_wino4<true, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
+                      : pa::launch_wino4<false, 2>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
+  else if (mode == 1)
+    rc = R != nullptr ? pa::launch_wino4<true, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
+                      : pa::launch_wino4<false, 1>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
+  else
+    rc = R != nullptr ? pa::launch_wino4<true, 0>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st)
+                      : pa::launch_wino4<false, 0>(X, B, H, W, cin, U, shift, R, Y, cout, relu, rows, st);
   if (rc != 0) return rc;
   PA_CHECK_LAUNCH("pa_conv3x3_wino4");
   return 0;

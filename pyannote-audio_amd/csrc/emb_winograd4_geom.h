@@ -181,4 +181,142 @@ __device__ __forceinline__ int wino4_lin_patch_lane(int piece, const Wino4LinTil
 __device__ __forceinline__ int wino4_lin_patch_base(int t, int g) { return 32 * t + 8 * (g ^ (2 * wino4_swz(t))); }
 constexpr int wino4_lin_patch_k(int i, int j) { return 512 * (6 * i + j); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RUN-shaped units (round 5, second form of the tile-linear units): the 16 consecutive tiles of a unit fall into at most
+// RMAX runs of tiles of ONE tile row; inside a run neighbouring tiles share their halo columns exactly as in the
+// row-shaped unit.  The patch is the row-shaped layout with the runs side by side: run r occupies the virtual columns
+// [4 C_r, 4 C_r + 4 n_r + 2) with C_0 = 0, C_{r+1} = C_r + n_r + 1 (n_r tiles: one 4-column slot of slack per run), i.e.
+// tile t of run r(t) sits at slot T' = t + r(t) and reads LDS row (4 py + column % 4) * PWQ + T' + column / 4 --
+// consecutive tiles, consecutive rows.  64 + 4 RMAX columns: 6 x 4 x 20 = 480 rows = 15 DMA pieces per stage (row-shaped
+// 13, tile-private 18) and 1.1x instead of 1.45x the patch bytes.  Maps with fewer than 6 tiles per row could need more
+// than RMAX runs: they keep the tile-private form.
+struct Wino4RunGeom {
+  static constexpr int CB = 8;
+  static constexpr int RMAX = 4;
+  static constexpr int PWQ = 16 + RMAX;              // slots per column residue
+  static constexpr int PROWS = 6 * 4 * PWQ;          // 480 LDS rows of 32 B
+  static constexpr int PINSTR = PROWS / 32;          // 15 DMA pieces of 1 KB per wave and stage
+  static constexpr int PATCH_BYTES = PINSTR * 1024;
+  static constexpr int USLAB_BYTES = Wino4Geom::USLAB_BYTES;
+  static constexpr int LDS_BYTES = 4 * PATCH_BYTES + 2 * USLAB_BYTES;   // 135 168
+};
+// the runs of unit u (wave-uniform).  The raster order continues into a VIRTUAL image behind the last one: tiles past
+// the end of the launch lie there (every pixel out of bounds: zeros), so no tile is ever repeated.
+struct Wino4Runs {   // (scalar members, not arrays: the compiler kept the array form in scratch memory)
+  int n;                                       // runs (1 .. RMAX)
+  int first0, first1, first2, first3, first4;  // first tile (0 .. 16) of run r; 16 from run n on
+  int b0, b1, b2, b3;                          // image of the run, relative to the unit's first image
+  int y0, y1, y2, y3;                          // top output row of the run's tiles
+  int x0, x1, x2, x3;                          // left output column of the run's first tile
+};
+__device__ __forceinline__ Wino4Runs wino4_runs(int u, int tcols, int trows, int* b0_out) {
+  static_assert(Wino4RunGeom::RMAX == 4, "four runs are spelled out");
+  Wino4Runs o;
+  const int per = tcols * trows;
+  int T = 16 * u;
+  const int img0 = T / per;
+  *b0_out = img0;
+  int t = 0;
+  o.n = 0;
+#define W4_RUN_STEP(r)                                                                    \
+  {                                                                                       \
+    o.first##r = t < 16 ? t : 16;                                                         \
+    const int b = T / per, rem = T - b * per, ty = rem / tcols, tx = rem - ty * tcols;   \
+    o.b##r = b - img0;                                                                    \
+    o.y##r = 4 * ty;                                                                      \
+    o.x##r = 4 * tx;                                                                      \
+    if (t < 16) {                                                                         \
+      int n = tcols - tx;                                                                 \
+      if (n > 16 - t) n = 16 - t;                                                         \
+      t += n;                                                                             \
+      T += n;                                                                             \
+      o.n = r + 1;                                                                        \
+    }                                                                                     \
+  }
+  W4_RUN_STEP(0) W4_RUN_STEP(1) W4_RUN_STEP(2) W4_RUN_STEP(3)
+#undef W4_RUN_STEP
+  o.first4 = 16;
+  return o;
+}
+// field f of run r for a per-LANE r: a chain of selects over the wave-uniform values (indexing the arrays with a
+// per-lane r would move them to scratch memory)
+// (as a sum of selected DIFFERENCES: a chain of selects on r == 0, 1, 2 is turned into a look-up table in scratch memory
+//  by the compiler, which costs a scratch load per field and lane)
+#define W4_RUN_SEL(R, f, r)                                                                             \
+  ((R).f##0 + ((r) >= 1 ? (R).f##1 - (R).f##0 : 0) + ((r) >= 2 ? (R).f##2 - (R).f##1 : 0) + \
+   ((r) >= 3 ? (R).f##3 - (R).f##2 : 0))
+#define W4_RUN_SEL_NEXT(R, f, r)                                                                        \
+  ((R).f##1 + ((r) >= 1 ? (R).f##2 - (R).f##1 : 0) + ((r) >= 2 ? (R).f##3 - (R).f##2 : 0) + \
+   ((r) >= 3 ? (R).f##4 - (R).f##3 : 0))
+// run of tile t / of patch slot `idx` (slot C_r + j holds tile j of run r and, for j = n_r, its right halo)
+__device__ __forceinline__ int wino4_run_of_tile(const Wino4Runs& R, int t) {
+  return (t >= R.first1) + (t >= R.first2) + (t >= R.first3);
+}
+__device__ __forceinline__ int wino4_run_of_slot(const Wino4Runs& R, int idx) {   // C_r = first[r] + r
+  return (idx >= R.first1 + 1) + (idx >= R.first2 + 2) + (idx >= R.first3 + 3);
+}
+// the tile of lane t (compute role)
+__device__ __forceinline__ Wino4LinTile wino4_run_tile(const Wino4Runs& R, int t, int u, int total_tiles) {
+  const int r = wino4_run_of_tile(R, t);
+  Wino4LinTile o;
+  o.valid = 16 * u + t < total_tiles;
+  o.b = W4_RUN_SEL(R, b, r);
+  o.y = W4_RUN_SEL(R, y, r);
+  o.x = W4_RUN_SEL(R, x, r) + 4 * (t - W4_RUN_SEL(R, first, r));
+  return o;
+}
+// DMA: piece i fills LDS rows 32 i .. 32 i + 31; lane l -> row 32 i + (l >> 1), 16-byte half l & 1 holding channel
+// quad (l & 1) ^ swz(slot).  -> byte offset from the first pixel of the unit's first image, or the out-of-bounds marker
+// (outside the image, in the slack of a run, in an unused slot, or in the virtual image behind the last one).
+__device__ __forceinline__ int wino4_run_patch_lane(int piece, const Wino4Runs& R, int H, int W, int CIN, int nimg_left,
+                                                   int lane) {
+  using G = Wino4RunGeom;
+  const int row = 32 * piece + (lane >> 1);
+  const int pr = row / G::PWQ, idx = row - pr * G::PWQ;   // pr = 4 py + residue
+  const int py = pr >> 2, v = 4 * idx + (pr & 3);          // virtual column
+  const int r = wino4_run_of_slot(R, idx);
+  const int first = W4_RUN_SEL(R, first, r), rb = W4_RUN_SEL(R, b, r);
+  const int nr = W4_RUN_SEL_NEXT(R, first, r) - first;     // tiles of the run (0: unused)
+  const int cx = v - 4 * (first + r);                      // column within the run's strip
+  const int iy = W4_RUN_SEL(R, y, r) - 1 + py, ix = W4_RUN_SEL(R, x, r) - 1 + cx;
+  const int quad = (lane & 1) ^ wino4_swz(idx);
+  const bool in = nr > 0 && cx < 4 * nr + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W && rb < nimg_left;
+  return in ? (((rb * H + iy) * W + ix) * CIN + 4 * quad) * 4 : WCLS_PAD;
+}
+// The same 15 offsets, the way the kernel computes them (the function above is the definition the host harness checks
+// this one against).  The LDS row of piece i is 32 i + (l >> 1) and 32 x 5 = 8 x PWQ: pieces i and i + 5 of a lane hit
+// the SAME slot and column residue, two patch rows further down -- so a lane looks up its run only five times per unit
+// (one chain of selects from the wave-uniform run table each), and every piece is an add, a row check and a select.
+__device__ __forceinline__ void wino4_run_patch_lanes(int (&off)[15], const Wino4Runs& R, int H, int W, int CIN,
+                                                      int nimg_left, int lane) {
+  using G = Wino4RunGeom;
+  static_assert(G::PINSTR == 15 && 32 * 5 == 8 * G::PWQ, "five-piece period of the lane -> slot map");
+  const int half = lane >> 1;
+  const int srow = W * CIN * 4;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int row = 32 * k + half;
+    const int pr = row / G::PWQ, idx = row - pr * G::PWQ;
+    const int py0 = pr >> 2, res = pr & 3;
+    const int r = wino4_run_of_slot(R, idx);
+    const int first = W4_RUN_SEL(R, first, r), nr = W4_RUN_SEL_NEXT(R, first, r) - first, rb = W4_RUN_SEL(R, b, r);
+    const int cx = 4 * (idx - first - r) + res;
+    const int ix = W4_RUN_SEL(R, x, r) - 1 + cx, ytop = W4_RUN_SEL(R, y, r) - 1;
+    const int quad = (lane & 1) ^ wino4_swz(idx);
+    const bool colok = nr > 0 && cx < 4 * nr + 2 && ix >= 0 && ix < W && rb < nimg_left;
+    const int base = (((rb * H + ytop) * W + ix) * CIN + 4 * quad) * 4;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int py = py0 + 2 * m;                  // (pieces k, k + 5, k + 10)
+      const int iy = ytop + py;
+      off[k + 5 * m] = (colok && iy >= 0 && iy < H) ? base + py * srow : WCLS_PAD;
+    }
+  }
+}
+// transform reads: lane (t, g) at slot T' = t + r(t): base(T', g, j >> 2) + K_ij
+__device__ __forceinline__ int wino4_run_patch_base(int slot, int g, int jq) {
+  return 32 * slot + 8 * (g ^ (2 * wino4_swz(slot + jq)));
+}
+constexpr int wino4_run_patch_k(int i, int j) { return 32 * ((4 * i + (j & 3)) * Wino4RunGeom::PWQ + (j >> 2)); }
+
 }  // namespace pa

@@ -221,7 +221,109 @@ static int check_lin_stack(int B, int H, int W, int CIN) {
   return 0;
 }
 
+// ---- run-shaped units (Wino4RunGeom): DMA and transform reads of unit u of a (B, H, W) stack of maps, stage c0
+static int check_run_unit(int B, int H, int W, int CIN, int u, int c0) {
+  using G = Wino4RunGeom;
+  const int tcols = (W + 3) / 4, trows = (H + 3) / 4, total = B * trows * tcols;
+  int b0 = 0;
+  const Wino4Runs R = wino4_runs(u, tcols, trows, &b0);
+  if (R.n < 1 || R.n > G::RMAX) return printf("run: bad run count\n"), 1;
+  {   // the runs cover the 16 tiles of the unit, in raster order (continuing into the virtual image behind the last)
+    int t = 0;
+    const int first[5] = {R.first0, R.first1, R.first2, R.first3, R.first4};
+    const int rb[4] = {R.b0, R.b1, R.b2, R.b3}, ry[4] = {R.y0, R.y1, R.y2, R.y3}, rx[4] = {R.x0, R.x1, R.x2, R.x3};
+    for (int r = 0; r < R.n; ++r) {
+      if (first[r] != t) return printf("run: first[] is not the prefix sum\n"), 1;
+      const int n = first[r + 1] - first[r];
+      if (n < 1) return printf("run: empty run\n"), 1;
+      const int T = 16 * u + t, b = T / (tcols * trows), rem = T % (tcols * trows);
+      if (b != b0 + rb[r] || 4 * (rem / tcols) != ry[r] || 4 * (rem % tcols) != rx[r]) return printf("run: origin\n"), 1;
+      if (rem % tcols + n > tcols) return printf("run: crosses a tile row\n"), 1;
+      t += n;
+    }
+    if (t != 16) return printf("run: %d runs do not cover the unit (tcols %d)\n", R.n, tcols), 1;
+  }
+  const long img = (long)H * W * CIN;
+  const long long rec = (long long)(B - b0) * img * 4 - 4LL * c0;
+  const unsigned num_records = (unsigned)(rec > 0x7fffffffLL ? 0x7fffffffLL : (rec < 0 ? 0 : rec));
+  std::vector<LinCell> lds((size_t)G::PINSTR * 64, LinCell{0, 0, 0, 0});
+  for (int lane = 0; lane < 64; ++lane) {
+    int fast[15];
+    wino4_run_patch_lanes(fast, R, H, W, CIN, B - b0, lane);     // what the kernel computes == the definition
+    for (int i = 0; i < G::PINSTR; ++i)
+      if (fast[i] != wino4_run_patch_lane(i, R, H, W, CIN, B - b0, lane))
+        return printf("run: the five-slot form of the lane offsets disagrees (piece %d lane %d)\n", i, lane), 1;
+  }
+  for (int lane = 0; lane < 64; ++lane)
+    for (int i = 0; i < G::PINSTR; ++i) {
+      const unsigned off = (unsigned)wino4_run_patch_lane(i, R, H, W, CIN, B - b0, lane);
+      LinCell& c = lds[(size_t)64 * i + lane];
+      if (c.kind != 0) return printf("run: LDS location written twice\n"), 1;
+      if (off >= num_records) {
+        c = LinCell{1, 0, 0, 0};
+      } else {
+        const long fl = (long)(off / 4) + c0;
+        if ((off % 16) != 0) return printf("run: bad offset\n"), 1;
+        const long within = fl % img;
+        c = LinCell{2, b0 + (int)(fl / img), within / CIN, (int)((within % CIN) - c0) / 4};
+        if (((within % CIN) - c0) % 4 != 0 || (within % CIN) - c0 < 0 || (within % CIN) - c0 >= G::CB)
+          return printf("run: channel quad out of the stage\n"), 1;
+      }
+    }
+  int conflicts = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      std::multiset<int> banks[2];
+      for (int lane = 0; lane < 64; ++lane) {
+        const int t = lane & 15, g = lane >> 4;
+        const int slot = t + wino4_run_of_tile(R, t);
+        const int addr = wino4_run_patch_base(slot, g, j >> 2) + wino4_run_patch_k(i, j);
+        if (addr % 8 != 0 || addr / 16 >= (int)lds.size()) return printf("run: read outside the patch block\n"), 1;
+        banks[lane >> 5].insert((addr / 4) % 64);
+        banks[lane >> 5].insert((addr / 4 + 1) % 64);
+        const LinCell& c = lds[addr / 16];
+        const Wino4LinTile tile = wino4_run_tile(R, t, u, total);
+        const int iy = tile.y - 1 + i, ix = tile.x - 1 + j, b = b0 + tile.b;
+        if (c.kind == 0) return printf("run: read of an LDS location the DMA never wrote\n"), 1;
+        if ((16 * u + t < total) != (tile.valid != 0)) return printf("run: tile validity\n"), 1;
+        const bool inside = b < B && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        if (inside) {
+          if (c.kind != 2 || c.b != b || c.gpix != (long)iy * W + ix || c.quad != (g >> 1) || ((addr % 16) / 8) != (g & 1))
+            return printf("run: unit %d lane %d (i=%d,j=%d): wrong element\n", u, lane, i, j), 1;
+        } else if (c.kind != 1) {
+          return printf("run: element (%d,%d) of image %d outside the stack is not a hardware zero\n", iy, ix, b), 1;
+        }
+      }
+      // the slots of a unit span 16 + (runs - 1) rows: two lanes 16 slots apart share their banks (a 2-way conflict on at
+      // most runs - 1 lane pairs per 32-lane group); everything else must be conflict free
+      for (int h = 0; h < 2; ++h) {
+        std::set<int> distinct(banks[h].begin(), banks[h].end());
+        conflicts += 64 - (int)distinct.size();
+        if ((int)distinct.size() < 64 - 4 * (R.n - 1)) return printf("run: more bank conflicts than the slack slots explain\n"), 1;
+      }
+    }
+  (void)conflicts;
+  return 0;
+}
+static int check_run_stack(int B, int H, int W, int CIN) {
+  const int tcols = (W + 3) / 4, trows = (H + 3) / 4, total = B * trows * tcols, units = (total + 15) / 16;
+  if (tcols < 5) return printf("run-shaped units need >= 5 tiles per row\n"), 1;
+  for (int u = 0; u < units; ++u) {
+    if (u > 3 && u < units - 4 && u % 5) continue;
+    for (int c0 = 0; c0 < CIN; c0 += CIN - 8 > 0 ? CIN - 8 : 8)
+      if (check_run_unit(B, H, W, CIN, u, c0)) return printf("  stack %dx%dx%dx%d unit %d stage %d\n", B, H, W, CIN, u, c0), 1;
+  }
+  return 0;
+}
+
 int main() {
+  static_assert(Wino4RunGeom::LDS_BYTES + 16 <= 160 * 1024, "run-shaped units: patch blocks + two U buffers must fit LDS");
+  {
+    const int stacks[][4] = {{3, 10, 38, 256}, {5, 20, 75, 128}, {2, 40, 149, 64}, {4, 17, 20, 32}, {7, 9, 18, 40},
+                             {2, 10, 125, 256}, {9, 5, 21, 40}, {1, 4, 64, 32}, {3, 3, 70, 64}, {6, 4, 17, 32}};
+    for (const auto& st : stacks)
+      if (check_run_stack(st[0], st[1], st[2], st[3])) return 1;
+  }
   static_assert(Wino4LinGeom::LDS_BYTES + 16 <= 160 * 1024, "linear units: patch blocks + two U buffers must fit LDS");
   {
     const int stacks[][4] = {{3, 10, 38, 256}, {5, 20, 75, 128}, {2, 40, 149, 64}, {7, 1, 1, 32}, {4, 17, 9, 32},

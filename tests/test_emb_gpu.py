@@ -230,20 +230,21 @@ def test_conv3x3_winograd_f4(gpu_device):
 
 
 @pytest.mark.parametrize("linear", ["1", "0"])
-def test_conv3x3_winograd_f4_unit_shapes(gpu_device, monkeypatch, linear):
-    """both unit shapes of the F(4x4) kernel on the SAME inputs: tile-linear units (16 consecutive tiles of the raster
-    order -- units straddle tile rows and images; what the launcher picks for the narrow maps of short chunks) and
-    row-shaped units (16 tiles of one tile row), forced through PA_WINO4_LINEAR in a fresh process-wide setting is not
-    possible (the switch is read once), so the test drives the launcher's own choice: narrow maps take linear units,
-    wide ones row units -- and checks every shape against torch: maps of 3 s chunks (40 x 149, 20 x 75, 10 x 38), maps
-    smaller than one unit, one tile per image (units of 16 images), ragged edges, with and without residual."""
+def test_conv3x3_winograd_f4_unit_shapes(gpu_device, linear):
+    """the unit shapes of the F(4x4) kernel through the launcher's own choice (the switch PA_WINO4_LINEAR is read once per
+    process): narrow maps with at least 5 tiles per row take RUN-shaped units (16 consecutive tiles of the raster order
+    -- units straddle tile rows and images -- laid out run by run with shared halos), narrower ones tile-private
+    patches, wide maps row-shaped units.  Every shape against torch: the maps of 3 s chunks (40 x 149, 20 x 75, 10 x 38),
+    maps smaller than one unit, one tile per image (units of 16 images), 5 / 6 tiles per row (four runs per unit),
+    ragged edges, more images than fit a launch group evenly, with and without residual; guard bands around the output
+    catch any store that strays out of its image."""
     import pyannote_audio_amd.ffi as ffi
     from pyannote_audio_amd.weights import winograd4_pack, winograd4_weights
     lib = ffi.load()
     g = torch.Generator().manual_seed(17 + int(linear))
     narrow = [(64, 64, 40, 149, 5, True), (128, 128, 20, 75, 7, False), (256, 256, 10, 38, 9, True),
               (32, 32, 3, 3, 37, True), (64, 32, 4, 4, 20, False), (32, 64, 6, 5, 3, True), (128, 128, 20, 75, 130, True),
-              (256, 256, 10, 38, 200, False)]
+              (256, 256, 10, 38, 200, False), (64, 64, 9, 18, 23, True), (32, 32, 7, 22, 41, False), (64, 64, 12, 21, 9, True)]
     wide = [(64, 64, 40, 499, 2, True), (128, 128, 20, 250, 3, False), (256, 256, 10, 125, 5, True)]
     for cin, cout, H, W, B, use_res in (narrow if linear == "1" else wide):
         x = torch.randn(B, cin, H, W, generator=g)
