@@ -55,6 +55,18 @@ def _nothing() -> None:
     pass
 
 
+class SolveFailed(RuntimeError):
+    """what the owner of a job shares instead of a solution when its solve step raised: every rank then raises (the
+    owner its own exception, the others this one) instead of waiting for a result that will not come"""
+
+    def __init__(self, owner: int, job: int, what: str):
+        super().__init__(f"rank {owner} failed to solve job {job}: {what}")
+        self.owner, self.job, self.what = owner, job, what
+
+    def __reduce__(self):
+        return SolveFailed, (self.owner, self.job, self.what)
+
+
 def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], None]], Any],
                     solve: Callable[[Any], Any], share: Callable[[int, int, Any, Any], Any],
                     finish: Callable[[Any, Any], Any], rank: int, world: int, depth: int = 0,
@@ -73,7 +85,9 @@ def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], Non
     tail thread picks the results up in order.  Up to `depth` jobs (default world + 1) are in flight before the main
     thread waits for the oldest; results come back in input order.  `solve` of job j starts when the front of job j + 1
     has called `release()` -- or has returned, or does not exist (as `pipelined`: the solve step must not run beside
-    the first stage of the next front).  Pure host logic: tests/test_pipelining_cpu.py."""
+    the first stage of the next front).  A solve step that raises is SHARED as a `SolveFailed` marker: the owner re-raises
+    its exception, every other rank raises the marker -- nobody is left waiting in `share`.  Pure host logic:
+    tests/test_pipelining_cpu.py."""
     depth = depth or world + 1
     log = logging.getLogger(__name__)
 
@@ -84,8 +98,17 @@ def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], Non
 
     def tail(j: int, state, solved):
         owner = j % world
-        solution = solved.result() if solved is not None else None     # (re-raises what `solve` raised)
-        return finish(state, share(j, owner, state, solution))
+        failure = None
+        try:
+            solution = solved.result() if solved is not None else None
+        except BaseException as exc:    # the owner's solve step failed: the other ranks are waiting in `share`
+            failure, solution = exc, SolveFailed(owner, j, f"{type(exc).__name__}: {exc}")
+        shared = share(j, owner, state, solution)
+        if failure is not None:
+            raise failure
+        if isinstance(shared, SolveFailed):
+            raise shared
+        return finish(state, shared)
 
     with ThreadPoolExecutor(max_workers=1) as solver, ThreadPoolExecutor(max_workers=1) as tails:
         in_flight = []          # (item, tail future), oldest first

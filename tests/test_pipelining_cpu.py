@@ -196,3 +196,59 @@ def test_owned_pipeline_surfaces_errors_and_single_rank_is_plain():
     with pytest.raises(RuntimeError, match="solve failed"):
         list(pipelined_owned(range(4), lambda it, rel: it, bad_solve, lambda j, o, st, sol: sol,
                              lambda st, sol: sol, rank=0, world=1))
+
+
+def _owned_failing_worker(rank, world, port, q):
+    import os
+    import pickle
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(list(range(world)), backend="gloo")
+    from pyannote_audio_amd.pipelining import pipelined_owned, SolveFailed
+
+    def solve(state):
+        if state == 3:                                            # job 3 belongs to rank 1
+            raise ValueError("no clusters today")
+        return state * 2
+
+    def share(j, owner, state, solution):                         # a pickled object, as parallel.broadcast_object
+        box = [solution if rank == owner else None]
+        dist.broadcast_object_list(box, src=owner, group=side)
+        return box[0]
+
+    got, err = [], None
+    try:
+        for item, out in pipelined_owned(range(6), lambda it, rel: it, solve, share, lambda st, sol: sol, rank, world):
+            got.append(out)
+    except (ValueError, SolveFailed) as exc:
+        err = (type(exc).__name__, str(exc))
+    q.put((rank, got, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owned_solve_failure_reaches_every_rank():
+    """the owner of job 3 raises in its solve step: it re-raises its own exception, the other rank raises SolveFailed
+    naming the owner and the job -- neither waits in the broadcast -- and jobs 0..2 were delivered on both"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_owned_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, got0, err0), (r1, got1, err1) = res
+    assert got0 == got1 == [0, 2, 4]
+    assert err1[0] == "ValueError" and "no clusters today" in err1[1]
+    assert err0[0] == "SolveFailed" and "rank 1 failed to solve job 3" in err0[1] and "no clusters today" in err0[1]
