@@ -547,7 +547,14 @@ class SpeakerDiarization(Pipeline):
         # on a third stream while its main stream goes on with the front ends, and the labels are broadcast over a
         # second process group in the tail thread) it runs at max(front end, clustering / world): the front end sets
         # the pace from two ranks on.  pipelining.pipelined_owned has the schedule.
-        group = self._label_group(shard)
+        try:
+            group = self._label_group(shard)
+        except Exception as exc:    # (no second process group on this installation: every rank clusters every job)
+            warnings.warn(f"apply_joint_batches: no process group for the label broadcasts ({exc}); "
+                          "the joint clustering runs redundantly on every rank")
+            for _, out in pipelined(groups, gather, finish, self.TAIL_GATE_TIMEOUT):
+                yield out
+            return
         solving = torch.cuda.Stream(device=device)
 
         def solve(job):
