@@ -417,9 +417,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    # PA_BENCH_SHARED_GPU=1 (functional check of the N > 1 code path on a ONE-GPU box, never a measurement): all ranks
+    # use cuda:0 and the process group is gloo -- RCCL refuses two ranks on one device
+    shared_gpu = os.environ.get("PA_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     exchange = dist.is_initialized()
     joint = exchange and (args.joint or (world > 1 and not args.per_file))
     if world != args.gpus:
@@ -482,7 +490,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if exchange:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return result, dt
@@ -570,6 +578,8 @@ def main():
             "roofline_others": others,
             "kernels": kernels,
         }
+        if shared_gpu:
+            line["functional_check_only"] = f"{world} ranks share cuda:0 over gloo (PA_BENCH_SHARED_GPU=1): not a measurement"
         if joint_info is not None:
             line["joint_clustering"] = joint_info
         if other is not None:
