@@ -179,13 +179,16 @@ def cpu_baseline(seg_o, emb_o, seconds: float, hour_artifacts=None, hours: float
     return res
 
 
-def load_traffic(kernel: str):
+def load_traffic(kernel: str, config: str = "pipeline"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; summarised by
     tools/pmc_traffic.py).  PMC counters cannot be read from inside this process, so the figure is a
-    STATIC one and says which file / commit it comes from."""
-    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r3a_traffic.json", "r2_traffic.json",
-                 "r1_traffic.json"):
+    STATIC one and says which file / commit it comes from.  A stage configuration (`--config seg5s|emb3s`) launches
+    the kernels on other shapes than the pipeline does: it only ever reads a capture of ITS OWN command
+    (profiles/r5_traffic_<config>.json, tools/capture_config_traffic.sh) -- or reports null."""
+    names = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r3a_traffic.json", "r2_traffic.json",
+             "r1_traffic.json") if config == "pipeline" else (f"r5_traffic_{config}.json",)
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fp:
                 d = json.load(fp)
@@ -197,14 +200,14 @@ def load_traffic(kernel: str):
     return None, None
 
 
-def roofline_entry(name: str, r: dict) -> dict:
+def roofline_entry(name: str, r: dict, config: str = "pipeline") -> dict:
     """`roofline` object for one kernel from the library profiler's record (HIP events on the launch
     stream): `achieved` is what the bounding unit really executed -- for the Winograd kernel the
     matrix pipe issues 16/36 of the direct convolution's multiplies, so `achieved` counts those and
     `frac` <= 1; the reference operation's (direct-convolution) rate is reported separately."""
     launches = max(r["launches"], 1)
     avg_ms = r["ms"] / launches
-    traffic, src = load_traffic(name)
+    traffic, src = load_traffic(name, config)
     if name in MFMA_KERNELS:
         algorithmic = r["flops"] / r["ms"] / 1e9
         executed = algorithmic * EXECUTED_FLOP_FRACTION.get(name, 1.0)
@@ -291,7 +294,7 @@ def bench_stage(args, pipeline, device, rank, config=None, steps=None, warmup=No
             "stage_algorithmic": {"tflops": round(stage_tflops, 2),
                                   "frac_of_f32_mfma_peak": round(stage_tflops / PEAK_MFMA_F32_TFLOPS, 4),
                                   "gflop_per_unit": per_unit_gflop},
-            "roofline": roofline_entry(dom, prof[dom]),
+            "roofline": roofline_entry(dom, prof[dom], config),
             "kernels": {k: {"launches": r["launches"], "ms": round(r["ms"], 3),
                             "tflops": round(r["flops"] / r["ms"] / 1e9, 2) if r["ms"] > 0 else None,
                             "gbs": round(r["bytes"] / r["ms"] / 1e6, 1) if r["ms"] > 0 else None}
