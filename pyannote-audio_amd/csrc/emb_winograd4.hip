@@ -850,14 +850,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   if (tid == 0) tq_done(tq, gridDim.x);
 }
 
-// row-shaped units pad every tile row to whole groups of 16 tiles, tile-linear units only the end of the launch, but
-// their tiles do not share halos: 18 instead of 13 patch pieces and 45 % more patch bytes per stage -- a unit costs
-// 1.14x (256 channels) to 1.24x (64 channels) as much (profiles/r5_wino4_linear_units.txt).  Linear when it has at least
-// 1.2x fewer units.  PA_WINO4_LINEAR=0 / 1 forces one of them (A/B aid).
-// -> 0 row-shaped, 1 tile-private, 2 run-shaped.  The run-shaped form keeps the shared halos of the row-shaped unit
-// (15 pieces, 1.1x its patch bytes: ~1.06x per unit) and is taken whenever it has at least 1.08x fewer units and the map
-// has at least 5 tiles per row (at most 4 runs per unit); the tile-private form serves narrower maps when it pays
-// (1.2x fewer units).  PA_WINO4_LINEAR=0 / 1 / 2 forces a form (A/B aid).
+// Which unit form a launch takes: 0 row-shaped, 1 tile-linear with tile-private patches, 2 tile-linear in run shape.
+// Row-shaped units pad every tile row to whole groups of 16 tiles; the tile-linear forms pad only the end of the
+// launch, and cost more per unit (measured, profiles/r5_wino4_linear_units.txt and r5_wino4_lin_anatomy.txt):
+//   tile-private  18 instead of 13 patch pieces and 1.45x the patch bytes per stage (no shared halos): 1.14x (256
+//                 channels) to 1.24x (64 channels) per unit -- taken when it leaves at least 1.2x fewer units;
+//   run-shaped    the shared halos of the row-shaped unit inside every run (15 pieces, 1.1x the bytes): 1.5-3.5 % less
+//                 per unit than the tile-private form, i.e. 1.14x - 1.22x a row-shaped unit -- taken when it leaves at
+//                 least 1.18x fewer units and the map has at least 5 tiles per row (a unit then spans at most 4 runs).
+// The maps of 10 s chunks (125 / 63 / 32 tiles per row) keep the row-shaped units; those of 3 s segments (38 / 19 / 10)
+// take the run-shaped ones.  PA_WINO4_LINEAR=0 / 1 / 2 forces a form (A/B aid).
 static int wino4_unit_mode(int B, int H, int W, int rows) {
   if (rows != H) return 0;                          // (row ranges: the row-shaped kernel)
   const long tcols = cdiv(W, 4), trows = cdiv(H, 4);
@@ -867,7 +869,7 @@ static int wino4_unit_mode(int B, int H, int W, int rows) {
     return m == 2 && tcols < 5 ? 1 : m;
   }
   const long lin_units = cdiv((long)B * trows * tcols, 16), row_units = (long)B * trows * cdiv(W, 64);
-  if (tcols >= 5 && lin_units * 108 <= row_units * 100) return 2;
+  if (tcols >= 5 && lin_units * 118 <= row_units * 100) return 2;
   return lin_units * 120 <= row_units * 100 ? 1 : 0;
 }
 
