@@ -13,7 +13,7 @@ from __future__ import annotations
 import logging
 import threading
 from concurrent.futures import ThreadPoolExecutor
-from typing import Any, Callable, Iterable, Iterator, Tuple
+from typing import Any, Callable, Iterable, Iterator, Sequence, Tuple
 
 
 def pipelined(items: Iterable[Any], front: Callable[[Any, Callable[[], None]], Any],
@@ -132,3 +132,27 @@ def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], Non
         finally:
             if gate is not None:
                 gate.set()
+
+
+class ReadAhead:
+    """`load(items[i + 1])` runs in ONE worker thread while the caller works on item i: `take(i)` hands out
+    `load(items[i])` (started by `take(i - 1)`, or now) and starts the next one.  At most one result is held ahead of
+    the caller; what `load` raises is raised by the `take` of its item.  (apply_batch: the next file is read from
+    disk while the GPU runs the current one.)"""
+
+    def __init__(self, items: Sequence[Any], load: Callable[[Any], Any]):
+        self._items, self._load = items, load
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._pending: dict = {}
+
+    def take(self, i: int):
+        if i not in self._pending:
+            self._pending[i] = self._pool.submit(self._load, self._items[i])
+        fut = self._pending.pop(i)
+        if i + 1 < len(self._items) and i + 1 not in self._pending:
+            self._pending[i + 1] = self._pool.submit(self._load, self._items[i + 1])
+        return fut.result()
+
+    def close(self) -> None:
+        self._pending.clear()
+        self._pool.shutdown(wait=False, cancel_futures=True)

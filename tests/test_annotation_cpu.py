@@ -106,3 +106,38 @@ def test_frame_geometry_matches_oracle(num_chunks, geom):
     for c in idx:
         s0, _ = ochunks.segment(c)
         assert starts[c] == oframes.closest_frame(s0 + 0.5 * oframes.duration)
+
+
+def test_flat_rows_rttm_and_serialize_from_columns_equal_the_dictionary_path():
+    """`flat_rows` (what `to_rttm` / `DiarizeOutput.serialize` read) lists a columnar annotation without building a
+    Segment per turn: same rows, same order as `itertracks` -- also with empty segments, several tracks per segment,
+    coarse (tied) times and shuffled input"""
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        n = 2000 if seed == 0 else 200
+        digits = 6 if seed < 2 else 1
+        starts = np.round(np.cumsum(rng.uniform(0.1, 1.0, n)), digits)
+        ends = starts + np.round(rng.uniform(0.0, 2.0, n), digits)
+        ends[::17] = starts[::17]                                  # empty segments: duration 0.000 in RTTM
+        labels = [f"SPEAKER_{int(k):02d}" for k in rng.integers(0, 4, n)]
+        tracks = list(rng.integers(0, 3, n))
+        k = 30                                                      # more tracks on the first segments
+        starts = np.concatenate([starts, starts[:k], starts[:k]])
+        ends = np.concatenate([ends, ends[:k], ends[:k]])
+        tracks = tracks + [7] * k + ["a"] * k
+        labels = labels + ["X"] * k + ["B"] * k
+        perm = rng.permutation(len(starts))
+        starts, ends = starts[perm], ends[perm]
+        tracks, labels = [tracks[i] for i in perm], [labels[i] for i in perm]
+        fast = Annotation.from_columns(starts, ends, tracks, labels, uri="u")
+        slow = Annotation.from_columns(starts, ends, tracks, labels, uri="u")
+        assert slow._tracks is not None and slow._cols is None      # (materialised: the dictionary path)
+        assert fast._cols is not None
+        want = [(s.start, s.end, t, l) for s, t, l in slow.itertracks(yield_label=True)]
+        assert fast.flat_rows() == want == slow.flat_rows()
+        assert fast._cols is not None, "listing the rows must not materialise the dictionary"
+        assert fast.to_rttm() == slow.to_rttm()
+        one = pa.DiarizeOutput(speaker_diarization=fast, exclusive_speaker_diarization=fast, speaker_embeddings=None)
+        two = pa.DiarizeOutput(speaker_diarization=slow, exclusive_speaker_diarization=slow, speaker_embeddings=None)
+        assert one.serialize() == two.serialize()
+    assert Annotation(uri="e").flat_rows() == [] and Annotation(uri="e").to_rttm() == ""

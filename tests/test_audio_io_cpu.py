@@ -139,3 +139,36 @@ def test_power_normalize_and_duration(wav_file):                   # core/io.py:
     assert Audio().get_duration({"waveform": torch.zeros(1, 24000), "sample_rate": 16000}) == 1.5
     with open(path, "rb") as f:
         assert Audio().get_duration(f) == 2.0 and f.tell() == 0
+
+
+def test_device_side_sample_conversion_equals_the_host_one(tmp_path):
+    """`Audio.load_on_device` copies the stored samples and scales them on the target device (here: the CPU, the
+    same torch operations); every stored format gives the bits of `Audio.__call__` -- power-of-two scalings -- and a
+    file with more than two channels takes the host path"""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(0)
+    n = 16000
+    cases = {"i16": (rng.standard_normal(n) * 8000).astype(np.int16),
+             "i16_stereo": (rng.standard_normal((n, 2)) * 8000).astype(np.int16),
+             "i16_three": (rng.standard_normal((n, 3)) * 8000).astype(np.int16),
+             "i32": (rng.standard_normal(n) * 2e8).astype(np.int32),
+             "u8": rng.integers(0, 256, n).astype(np.uint8),
+             "f32": (rng.standard_normal(n) * 0.1).astype(np.float32)}
+    audio = Audio(sample_rate=16000, mono="downmix")
+    for name, data in cases.items():
+        path = tmp_path / f"{name}.wav"
+        wavfile.write(str(path), 16000, data)
+        want, sr = audio(str(path))
+        got, sr2 = audio.load_on_device(str(path), torch.device("cpu"))
+        assert sr == sr2 == 16000 and got.dtype == torch.float32 and torch.equal(got, want), name
+        raw = Audio._read_raw(str(path))                               # what apply_batch reads one file ahead
+        assert torch.equal(audio.load_on_device({"audio": str(path)}, torch.device("cpu"), raw=raw)[0], want)
+        assert torch.equal(audio.load_on_device({"audio": str(path), "channel": 0}, torch.device("cpu"))[0],
+                           audio({"audio": str(path), "channel": 0})[0])
+    # the historical host conversion (numpy: astype + divide) gives the same bits as the torch one used now
+    assert np.array_equal(cases["i16"].astype(np.float32) / 32768.0, audio(str(tmp_path / "i16.wav"))[0][0].numpy())
+    assert np.array_equal((cases["u8"].astype(np.float32) - 128.0) / 128.0, audio(str(tmp_path / "u8.wav"))[0][0].numpy())
+    assert np.array_equal(cases["i32"].astype(np.float32) / 2147483648.0, audio(str(tmp_path / "i32.wav"))[0][0].numpy())
+    # a waveform mapping passes through
+    wav = torch.randn(1, 100)
+    assert torch.equal(audio.load_on_device({"waveform": wav, "sample_rate": 16000}, torch.device("cpu"))[0], wav)

@@ -46,6 +46,41 @@ def test_apply_batch_equals_sequential(pipeline_dir, gpu_device):
         pipeline([files[0], dict(files[1], uri=files[0]["uri"])])
 
 
+def test_files_on_disk_equal_resident_waveforms(pipeline_dir, gpu_device, tmp_path):
+    """WAV files on disk (the reference CLI's input, __main__.py:684-744): the stored 16-bit samples go to the device as
+    they are and are scaled there (`Audio.load_on_device`), and `apply_batch` reads file i + 1 in a worker thread while
+    the GPU runs file i -- results identical to the same samples handed over as float32 waveforms, for a list, a
+    single path, a stereo file and a file object; a missing file raises where the reference raises (validation)."""
+    from scipy.io import wavfile
+    import pyannote_audio_amd as pa
+    from pyannote_audio_amd.audio import Audio
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir).to(gpu_device)
+    files = _files([(33.0, 5), (12.0, 3), (27.3, 8)])
+    on_disk, resident = [], []
+    for f in files:
+        pcm = (f["waveform"][0].clamp(-1, 1) * 32767.0).round().to(torch.int16).numpy()
+        if f["uri"] == "f3":                                   # one stereo file: down-mixed on the device
+            pcm = np.stack([pcm, pcm[::-1]], axis=1)
+        path = str(tmp_path / (f["uri"] + ".wav"))
+        wavfile.write(path, 16000, pcm)
+        on_disk.append({"audio": path, "uri": f["uri"]})
+        host = Audio(16000, "downmix")(path)[0]                # the host conversion of the same file
+        assert torch.equal(Audio(16000, "downmix").load_on_device(path, gpu_device)[0].cpu(), host)
+        resident.append({"waveform": host, "sample_rate": 16000, "uri": f["uri"]})
+    want = [out for _, out in pipeline(resident)]
+    got = list(pipeline(on_disk))
+    assert [f["uri"] for f, _ in got] == [f["uri"] for f in on_disk]
+    for (f, out), ref in zip(got, want):
+        assert _turns(out.speaker_diarization) == _turns(ref.speaker_diarization), f["uri"]
+        assert np.array_equal(out.speaker_embeddings, ref.speaker_embeddings)
+    single = pipeline(on_disk[0]["audio"])
+    assert _turns(single.speaker_diarization) == _turns(want[0].speaker_diarization)
+    with open(on_disk[1]["audio"], "rb") as fp:
+        assert _turns(pipeline(fp).speaker_diarization) == _turns(want[1].speaker_diarization)
+    with pytest.raises(ValueError, match="does not exist"):
+        list(pipeline([on_disk[0], {"audio": str(tmp_path / "missing.wav"), "uri": "m"}]))
+
+
 def test_apply_batch_honours_per_file_pipeline_kwargs(pipeline_dir, gpu_device):
     """core/pipeline.py:583: every file of a list is applied with ITS `pipeline_kwargs`; a name given both
     per file and per batch is the TypeError a double keyword is."""
