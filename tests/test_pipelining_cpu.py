@@ -20,7 +20,7 @@ def test_results_in_order_and_tail_waits_for_the_release_of_the_next_front():
         time.sleep(0.02)              # "segmentation": the previous tail must not have started yet
         note("release", item)
         release()
-        time.sleep(0.05)              # "embeddings": the previous tail runs beside this
+        time.sleep(0.25)              # "embeddings": the previous tail runs beside this (long enough for a loaded machine)
         note("front-end", item)
         return item * 10
 
@@ -270,6 +270,9 @@ def test_read_ahead_loads_one_item_ahead_in_order_and_raises_at_the_right_take()
 
     ahead = ReadAhead(["a", "b", "bad", "d"], load)
     assert ahead.take(0) == "A"
+    deadline = time.time() + 5.0
+    while len(started) < 2 and time.time() < deadline:
+        time.sleep(0.005)
     time.sleep(0.05)
     assert started == ["a", "b"]                  # item 1 was started by take(0); item 2 not yet
     assert ahead.take(1) == "B"
