@@ -172,3 +172,23 @@ def test_device_side_sample_conversion_equals_the_host_one(tmp_path):
     # a waveform mapping passes through
     wav = torch.randn(1, 100)
     assert torch.equal(audio.load_on_device({"waveform": wav, "sample_rate": 16000}, torch.device("cpu"))[0], wav)
+
+
+def test_what_apply_batch_reads_ahead(tmp_path):
+    """only a file on DISK is read ahead (worker thread, host only): resident waveforms and file objects are left to
+    the front end itself"""
+    import io
+    from scipy.io import wavfile
+    import pyannote_audio_amd as pa
+    data = (np.random.default_rng(1).standard_normal(800) * 5000).astype(np.int16)
+    path = tmp_path / "a.wav"
+    wavfile.write(str(path), 8000, data)
+    read_ahead = pa.SpeakerDiarization._read_ahead
+    raw, rate = read_ahead({"audio": str(path), "uri": "a"})
+    assert rate == 8000 and raw.dtype == np.int16 and np.array_equal(raw, data)
+    raw2, _ = read_ahead({"audio": path, "uri": "a"})                 # a pathlib.Path
+    assert np.array_equal(raw2, data)
+    assert read_ahead({"waveform": torch.zeros(1, 10), "sample_rate": 8000, "audio": str(path)}) is None
+    with open(path, "rb") as fp:
+        assert read_ahead({"audio": fp, "uri": "stream"}) is None
+    assert read_ahead({"audio": io.BytesIO(path.read_bytes()), "uri": "stream"}) is None
