@@ -37,6 +37,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with `hipIpcGetMemHandle: invalid
+# argument`); the variable is exported on the boxes already -- kept here for an environment built by hand
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
