@@ -1,7 +1,8 @@
 #!/bin/bash
 # round-end validation on the GPU box: full GPU suite, default bench line, smoke, N = 1 under torchrun (the
 # configs[4] code path with one rank), then tools/capture_profiles.sh (kernel stats + PMC passes at HEAD)
-# usage (via gpurun): bash tools/final_check.sh r3
+# usage (via gpurun): [SKIP_LINKAGE=1] bash tools/final_check.sh r5      (the per-configuration PMC traffic of
+# bench.py's `configs` entries: sh tools/capture_config_traffic.sh r5, its own call)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 tag=${1:-r3}
