@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- audio-hours/s of the speaker-diarization-3.1 hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: under torch.distributed.run, or plain -- the script then
+                                                          starts its N ranks itself, `self_launch`)
 
 One "step" = one pass of the whole pipeline (`Pipeline.__call__` -> sliding-window PyanNet
 segmentation -> speaker counting -> WeSpeaker ResNet34 embeddings -> agglomerative clustering ->
@@ -394,6 +395,25 @@ def bench_reference_metric(pipeline, wav: torch.Tensor, hours: float, num_files:
         shutil.rmtree(root, ignore_errors=True)
 
 
+def self_launch(n_gpus: int, argv=None) -> int:
+    """`python bench.py --gpus N` without a launcher: re-executes this command under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on a free local port (one process per GPU, RCCL
+    over xGMI; rank 0 prints the JSON line on the inherited stdout) and returns its exit status -- non-zero as soon
+    as any rank dies (torch.distributed.run tears the others down)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,6 +439,9 @@ def main():
                          "configs[2] (`configs`) and the host-resident single file (`ingest`)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

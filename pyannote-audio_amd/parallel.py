@@ -109,6 +109,18 @@ def all_gather_chunks(seg_local, emb_local, total_chunks: int, shard: Shard, dev
     return unpack_records(torch.cat(parts, dim=0), F, S, D)
 
 
+def agree_all(flag: bool, shard: Shard, device: torch.device) -> bool:
+    """True iff `flag` is true on EVERY rank of `shard` (one all-reduce(MIN) on the shard's own group): how ranks choose
+    between code paths that issue different collectives, so that a rank with another environment or a local failure
+    cannot take one schedule while the others wait for it inside the other."""
+    if shard.world_size == 1:
+        return bool(flag)
+    wire = _wire_device(shard, device)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=wire)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=shard.group)
+    return bool(int(t.item()))
+
+
 def broadcast_object(obj, src: int, shard: Shard, group, device: torch.device):
     """a small picklable object (the cluster labels and centroids of a joint job: numpy arrays) from rank `src` to
     every rank of `group`: its size, then its bytes (two broadcasts; through device memory when `group` is an RCCL

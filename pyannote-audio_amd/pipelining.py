@@ -110,28 +110,38 @@ def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], Non
             raise shared
         return finish(state, shared)
 
-    with ThreadPoolExecutor(max_workers=1) as solver, ThreadPoolExecutor(max_workers=1) as tails:
-        in_flight = []          # (item, tail future), oldest first
-        gate = None             # gate of the newest job's solve step
-        try:
-            for j, item in enumerate(items):
-                state = front(item, gate.set if gate is not None else _nothing)
-                if gate is not None:
-                    gate.set()
-                gate = threading.Event()
-                solved = solver.submit(gated_solve, state, gate) if j % world == rank else None
-                in_flight.append((item, tails.submit(tail, j, state, solved)))
-                while len(in_flight) > depth:
-                    done_item, fut = in_flight.pop(0)
-                    yield done_item, fut.result()
+    # (not `with` blocks: leaving one WAITS for the queued tails -- which sit in `share` collectives that the other ranks
+    #  only answer if this rank keeps going -- so a local error in `front` or in the consumer would turn into a hang
+    #  until the process group's timeout.  On the error path the executors are dropped without waiting and what is
+    #  queued is cancelled: the local exception surfaces at once.  The job is lost on every rank then -- the caller has
+    #  to abort the other ranks (they time out in `share` otherwise); a tail already inside a collective cannot be
+    #  interrupted and keeps its thread until that collective fails.)
+    solver, tails = ThreadPoolExecutor(max_workers=1), ThreadPoolExecutor(max_workers=1)
+    in_flight = []          # (item, tail future), oldest first
+    gate = None             # gate of the newest job's solve step
+    clean = False
+    try:
+        for j, item in enumerate(items):
+            state = front(item, gate.set if gate is not None else _nothing)
             if gate is not None:
                 gate.set()
-            while in_flight:
+            gate = threading.Event()
+            solved = solver.submit(gated_solve, state, gate) if j % world == rank else None
+            in_flight.append((item, tails.submit(tail, j, state, solved)))
+            while len(in_flight) > depth:
                 done_item, fut = in_flight.pop(0)
                 yield done_item, fut.result()
-        finally:
-            if gate is not None:
-                gate.set()
+        if gate is not None:
+            gate.set()
+        while in_flight:
+            done_item, fut = in_flight.pop(0)
+            yield done_item, fut.result()
+        clean = True
+    finally:
+        if gate is not None:
+            gate.set()
+        solver.shutdown(wait=clean, cancel_futures=not clean)
+        tails.shutdown(wait=clean, cancel_futures=not clean)
 
 
 class ReadAhead:

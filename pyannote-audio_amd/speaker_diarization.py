@@ -557,7 +557,7 @@ class SpeakerDiarization(Pipeline):
             return out
 
         shard = parallel.shard_from_env() if parallel.current_shard().world_size == 1 else parallel.Shard()
-        if shard.world_size == 1 or os.environ.get("PA_JOINT_OWNERS", "1") == "0":
+        if shard.world_size == 1:
             for _, out in pipelined(groups, gather, finish, self.TAIL_GATE_TIMEOUT):
                 yield out
             return
@@ -568,18 +568,18 @@ class SpeakerDiarization(Pipeline):
         # on a third stream while its main stream goes on with the front ends, and the labels are broadcast over a
         # second process group in the tail thread) it runs at max(front end, clustering / world): the front end sets
         # the pace from two ranks on.  pipelining.pipelined_owned has the schedule.
-        try:
-            group = self._label_group(shard)
-        except Exception as exc:    # (no second process group on this installation: every rank clusters every job)
-            warnings.warn(f"apply_joint_batches: no process group for the label broadcasts ({exc}); "
-                          "the joint clustering runs redundantly on every rank")
+        # The two schedules do not mix (a rank inside `pipelined` never answers the broadcasts the others wait for):
+        # the choice is AGREED ON by all ranks -- the minimum of everybody's PA_JOINT_OWNERS -- and a rank that
+        # cannot create the label group raises on every rank's side of that collective instead of falling back alone.
+        if not parallel.agree_all(os.environ.get("PA_JOINT_OWNERS", "1") != "0", shard, device):
             for _, out in pipelined(groups, gather, finish, self.TAIL_GATE_TIMEOUT):
                 yield out
             return
+        group = self._label_group(shard)
         solving = torch.cuda.Stream(device=device)
 
         def solve(job):
-            if job["empty"] or not len(job["all_emb"]):
+            if job["empty"] or not job["all_emb_dev"].shape[0]:
                 return None
             with torch.cuda.device(device), torch.cuda.stream(solving):
                 solution = self._joint_cluster(job, bounds)
@@ -654,8 +654,10 @@ class SpeakerDiarization(Pipeline):
             embs = [fr.dev_emb for fr in voiced]
             mine = list(range(len(voiced)))
         all_emb_dev = torch.cat(embs, dim=0).contiguous()
+        # (the host copy of the gathered embeddings -- 88 MB at eight one-hour files -- is made by the rank that
+        #  clusters the job, `_joint_cluster`, not by every rank here)
         job.update(sizes=[s.shape[0] for s in segs], mine=mine, all_seg=torch.cat(segs, dim=0).contiguous(),
-                   all_emb=all_emb_dev.cpu().numpy(), all_emb_dev=all_emb_dev)
+                   all_emb_dev=all_emb_dev)
         torch.cuda.current_stream(device).synchronize()   # the second half may run on another stream
         return job
 
@@ -671,7 +673,7 @@ class SpeakerDiarization(Pipeline):
     def _joint_cluster(self, job: dict, bounds):
         """the ONE clustering of a joint job over the records of all files of all ranks -> (hard, centroids)"""
         num_speakers, min_speakers, max_speakers = bounds
-        all_seg, all_emb = job["all_seg"], job["all_emb"]
+        all_seg, all_emb = job["all_seg"], job["all_emb_dev"].cpu().numpy()
         _, clean = frame_ops.chunk_stats(all_seg)
         # the clustering only reads the SHAPE of the segmentations when the clean-frame counts are given
         seg_view = SlidingWindowFeature(all_seg.cpu().numpy(), self._chunk_grid())

@@ -109,6 +109,10 @@ def _worker(rank, world, port, total, q, port2=None):
         ok = ok and got[0].dtype == np.int8 and np.array_equal(got[0], np.arange(12, dtype=np.int8).reshape(4, 3) * (src + 1)) \
             and got[1].shape == (2, 5)
     ok = ok and parallel.broadcast_object(None if rank == 1 else "x", 1, shard, side, torch.device("cpu")) is None
+    # the choice between two collective schedules is agreed on: true only when every rank says so
+    ok = ok and parallel.agree_all(True, shard, torch.device("cpu")) is True
+    ok = ok and parallel.agree_all(rank == 0, shard, torch.device("cpu")) is False
+    ok = ok and parallel.agree_all(False, shard, torch.device("cpu")) is False
     q.put((rank, b, e, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -199,6 +199,30 @@ def test_owned_pipeline_surfaces_errors_and_single_rank_is_plain():
                              lambda st, sol: sol, rank=0, world=1))
 
 
+def test_owned_front_error_surfaces_while_a_tail_is_stuck_in_its_collective():
+    """rank 1 of 2 (emulated: `share` blocks like a broadcast nobody answers): job 0's tail sits in `share` when the
+    front of job 1 raises -- the exception reaches the caller at once instead of after the tail's collective gives up"""
+    import threading
+    from pyannote_audio_amd.pipelining import pipelined_owned
+    stuck = threading.Event()
+
+    def front(item, release):
+        if item == 1:
+            time.sleep(0.2)        # (job 0's tail is inside `share` by now)
+            raise KeyError("bad file")
+        return item
+
+    def share(j, owner, state, solution):
+        stuck.wait(timeout=30.0)   # the other rank never comes
+        return solution
+
+    t0 = time.perf_counter()
+    with pytest.raises(KeyError, match="bad file"):
+        list(pipelined_owned(range(3), front, lambda st: st, share, lambda st, sol: sol, rank=1, world=2))
+    assert time.perf_counter() - t0 < 5.0
+    stuck.set()                    # (let the worker thread go)
+
+
 def _owned_failing_worker(rank, world, port, q):
     import os
     import pickle

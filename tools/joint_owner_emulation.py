@@ -27,7 +27,7 @@ sd = pipeline   # SpeakerDiarization
 bounds = sd._speaker_bounds(None, None, None, {})
 files = [{"waveform": synth_hour(1.0, seed=100 + i, device=dev), "sample_rate": 16000, "uri": f"h{i}"} for i in range(world)]
 job8 = sd._joint_gather([Audio.validate_file(f) for f in files], None, dev)     # records of all 8 files
-print(f"gathered {sum(job8['sizes'])} chunks of {world} files; {len(job8['all_emb'])} x {job8['all_emb'].shape[1:]} embeddings")
+print(f"gathered {sum(job8['sizes'])} chunks of {world} files; {len(job8['all_emb_dev'])} x {tuple(job8['all_emb_dev'].shape[1:])} embeddings")
 cached = sd._joint_cluster(job8, bounds)          # (also warms the allocator: the first call pays ~1 s of hipMalloc)
 torch.cuda.synchronize()
 side, solving = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
