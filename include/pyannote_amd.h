@@ -178,6 +178,9 @@ typedef struct pa_emb_weights {
    * runs through pa_conv3x3_wino4 instead of pa_conv3x3_wino (blk_u*) / pa_conv3x3 (blk_w*) */
   const float* blk_v1[PA_MAX_RES_BLOCKS];
   const float* blk_v2[PA_MAX_RES_BLOCKS];
+  /* fbank centring (wespeaker/__init__.py:137-157): 0 = subtract the mean over all frames of the chunk
+   * (fbank_centering_span=None); odd K >= 1 = subtract the running mean of K frames (pa_fbank_center_span) */
+  int32_t fb_center_kernel;
 } pa_emb_weights;
 
 /* fbank frames for num_samples (25 ms / 10 ms, snip_edges) and frames after the 3 stride-2 stages */
@@ -211,6 +214,11 @@ int pa_absmax_diff(const float* got, const float* ref, long n, float* out2, void
 int pa_fbank(const float* wav, long wav_len, long chunk_stride, int B, int N, const float* window,
              const float* tw256, const float* tw512, const float* mel_w, const int* mel_lo,
              const int* mel_hi, int nmel, float* out, int center, void* stream);
+/* Running-mean centring of fbank features, out of place (wespeaker/__init__.py:141-157): for every chunk b, frame t and
+ * mel bin m,  out[b][t][m] = fb[b][t][m] - mean(fb[b][t - K/2 .. t + K/2][m] inside [0, T)),  the mean being the float32
+ * sum in ascending frame order divided by the number of frames inside -- F.avg_pool1d(kernel K, stride 1, padding K / 2,
+ * count_include_pad=False).  fb, out: (B, T, nmel) float32, out != fb; K odd >= 1; min(K, 2 T - 1) <= 2049. */
+int pa_fbank_center_span(const float* fb, int B, int T, int nmel, int kernel, float* out, void* stream);
 int pa_resnet_stem(const float* fbank, int B, int T, int F, const float* w9, const float* shift,
                    float* out, void* stream);
 int pa_conv3x3(const float* X, int B, int H, int W, int cin, const float* Wg, const float* shift,

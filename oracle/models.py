@@ -430,12 +430,13 @@ class WeSpeakerResNet34(nn.Module):
     """fbank -> ResNet34 -> TSTP -> Linear(5120, 256)  (wespeaker/__init__.py:324-372)."""
 
     def __init__(self, sample_rate=16000, num_mel_bins=80, frame_length=25, frame_shift=10,
-                 num_blocks=(3, 4, 6, 3), block=None):
+                 num_blocks=(3, 4, 6, 3), block=None, fbank_centering_span=None):
         super().__init__()
         self.sample_rate = sample_rate
         self.num_mel_bins = num_mel_bins
         self.frame_length = frame_length
         self.frame_shift = frame_shift
+        self.fbank_centering_span = fbank_centering_span     # seconds, or None (wespeaker/__init__.py:56-71)
         # block=Bottleneck with (3, 8, 36, 3) / (6, 16, 48, 3) / (10, 20, 64, 3) = WeSpeakerResNet152 /
         # 221 / 293 (wespeaker/__init__.py:375-470, resnet.py:477-507)
         self.resnet = ResNet(num_blocks, 32, num_mel_bins, 256, block=block)
@@ -446,7 +447,16 @@ class WeSpeakerResNet34(nn.Module):
             kaldi_fbank(w, num_mel_bins=self.num_mel_bins, frame_length=self.frame_length,
                         frame_shift=self.frame_shift, sample_frequency=self.sample_rate)
             for w in waveforms])
-        return feats - torch.mean(feats, dim=1, keepdim=True)
+        if self.fbank_centering_span is None:                        # wespeaker/__init__.py:137-139
+            return feats - torch.mean(feats, dim=1, keepdim=True)
+        # running average over `fbank_centering_span` seconds (wespeaker/__init__.py:141-157): the span in frames
+        # (conv1d_num_frames of the fbank framing, utils/receptive_field.py:26-53), made odd, as an average pooling
+        # that does not count the padding
+        window_size = int(self.sample_rate * self.frame_length * 0.001)
+        step_size = int(self.sample_rate * self.frame_shift * 0.001)
+        kernel_size = 1 + (int(self.fbank_centering_span * self.sample_rate) - (window_size - 1) - 1) // step_size
+        return feats - F.avg_pool1d(feats.transpose(1, 2), kernel_size=2 * (kernel_size // 2) + 1, stride=1,
+                                    padding=kernel_size // 2, count_include_pad=False).transpose(1, 2)
 
     def forward(self, waveforms, weights=None):
         return self.resnet(self.compute_fbank(waveforms), weights=weights)

@@ -7,6 +7,7 @@
 //                    real FFT as a 256-point complex radix-4 Stockham FFT in LDS + real unpack, power,
 //                    sparse mel projection, log(max(., eps)).
 //   k_fbank_center   subtract the per-chunk mean over frames (wespeaker/__init__.py:138-139).
+//   k_fbank_center_span   subtract the running mean of K frames (wespeaker/__init__.py:141-157).
 #include "common.h"
 
 namespace pa {
@@ -178,9 +179,65 @@ __global__ __launch_bounds__(320) void k_fbank_center(float* __restrict__ fb, in
     for (int t = p; t < T; t += 4) x[(long)t * nmel + m] -= mean;
 }
 
+// Running-mean centring (wespeaker/__init__.py:141-157, fbank_centering_span given): out = x - avg_pool1d(x, K, stride 1,
+// padding K / 2, count_include_pad=False) along the frames.  One workgroup per (chunk, group of 16 mel bins, tile of
+// FC_TT frames): the tile and its K / 2 frames of halo on either side go to LDS once ([frame][16 bins]: the 64 lanes of a
+// wave read 4 consecutive frames x 16 bins = 64 consecutive words, conflict-free), then every thread adds up the K
+// frames of its outputs in ASCENDING order in float32 and divides by the number of frames inside the chunk -- the
+// reference's arithmetic, not a sliding sum.  Out of place: the neighbouring tiles read this tile's frames.
+constexpr int FC_TT = 240, FC_MG = 16, FC_KMAX = 2049;   // (240 + 2048) x 64 B = 143 KB of LDS
+__global__ __launch_bounds__(256) void k_fbank_center_span(const float* __restrict__ fb, int T, int nmel, int K,
+                                                           float* __restrict__ out) {
+  extern __shared__ float fc_tile[];   // [(FC_TT + K - 1)][FC_MG]
+  const int b = blockIdx.z, m0 = blockIdx.y * FC_MG, t0 = blockIdx.x * FC_TT;
+  const int half = K >> 1;
+  const int m = threadIdx.x & (FC_MG - 1), tl = threadIdx.x >> 4;     // 16 bins x 16 frame lanes
+  const float* x = fb + (long)b * T * nmel;
+  const int rows = FC_TT + K - 1;
+  for (int r = tl; r < rows; r += 16) {
+    const int t = t0 - half + r;
+    fc_tile[r * FC_MG + m] = (t >= 0 && t < T && m0 + m < nmel) ? x[(long)t * nmel + m0 + m] : 0.f;
+  }
+  __syncthreads();
+  if (m0 + m >= nmel) return;
+  for (int i = tl; i < FC_TT; i += 16) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    const int lo = t - half < 0 ? 0 : t - half, hi = t + half > T - 1 ? T - 1 : t + half;
+    float s = 0.f;
+    for (int u = lo; u <= hi; ++u) s += fc_tile[(u - t0 + half) * FC_MG + m];
+    out[((long)b * T + t) * nmel + m0 + m] = fc_tile[(i + half) * FC_MG + m] - s / (float)(hi - lo + 1);
+  }
+}
+
 }  // namespace pa
 
 extern "C" {
+
+// wespeaker/__init__.py:141-157 (compute_fbank with fbank_centering_span): see include/pyannote_amd.h
+int pa_fbank_center_span(const float* fb, int B, int T, int nmel, int kernel, float* out, void* stream) {
+  PA_REQUIRE(kernel >= 1 && (kernel & 1), "pa_fbank_center_span: the window must be an odd number of frames (got %d)",
+             kernel);
+  PA_REQUIRE(fb != out, "pa_fbank_center_span: works out of place");
+  if (B <= 0 || T <= 0 || nmel <= 0) return 0;
+  // a window that reaches past both ends of the chunk from every frame is clipped to [0, T) anyway: 2 T - 1 frames
+  // give the same sums in the same order
+  if (kernel > 2 * T - 1) kernel = 2 * T - 1;
+  PA_REQUIRE(kernel <= pa::FC_KMAX,
+             "pa_fbank_center_span: a running mean over %d frames of a %d-frame chunk needs more than the LDS holds "
+             "(at most %d frames)", kernel, T, pa::FC_KMAX);
+  const size_t lds = (size_t)(pa::FC_TT + kernel - 1) * pa::FC_MG * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pa::k_fbank_center_span, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((pa::FC_TT + pa::FC_KMAX - 1) * pa::FC_MG * sizeof(float)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pa::k_fbank_center_span, dim3(pa::cdiv(T, pa::FC_TT), pa::cdiv(nmel, pa::FC_MG), B), dim3(256), lds,
+                     (hipStream_t)stream, fb, T, nmel, kernel, out);
+  PA_CHECK_LAUNCH("pa_fbank_center_span");
+  return 0;
+}
 
 // wespeaker/__init__.py:113-139 (compute_fbank, fbank_centering_span=None)
 int pa_fbank(const float* wav, long wav_len, long chunk_stride, int B, int N, const float* window,

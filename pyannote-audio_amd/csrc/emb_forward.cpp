@@ -156,12 +156,21 @@ static int emb_forward_impl(const pa_emb_weights* w, const float* wav, int64_t w
     if (rc != 0) return rc; \
   } while (0)
 
+  // fbank + centring: the mean over the whole chunk (fused behind the fbank kernel), or -- fbank_centering_span, a
+  // checkpoint hyper-parameter -- the running mean of fb_center_kernel frames, out of place into the second
+  // activation buffer (free until the first residual block), which the stem then reads
+  const int span = w->fb_center_kernel;
   RUN(pa_fbank(wav, wav_len, chunk_stride, B, p.N, w->fb_window, w->fb_tw256, w->fb_tw512, w->fb_mel_w,
-               w->fb_mel_lo, w->fb_mel_hi, w->num_mel, ws + p.fbank, 1, stream));
+               w->fb_mel_lo, w->fb_mel_hi, w->num_mel, ws + p.fbank, span == 0 ? 1 : 0, stream));
   float* cur = ws + p.act[0];
   float* f1 = ws + p.act[1];
   float* f2 = ws + p.act[2];
-  RUN(pa_resnet_stem(ws + p.fbank, B, p.T, p.F, w->stem_w, w->stem_shift, cur, stream));
+  const float* feats = ws + p.fbank;
+  if (span != 0) {
+    RUN(pa_fbank_center_span(ws + p.fbank, B, p.T, p.F, span, f1, stream));
+    feats = f1;
+  }
+  RUN(pa_resnet_stem(feats, B, p.T, p.F, w->stem_w, w->stem_shift, cur, stream));
 
   // a stride-1 3x3 convolution (+ shift, residual R, ReLU) of a BasicBlock: F(4x4) where it pays, else F(2x2), else
   // the direct kernel -- as far as the block carries the images (the numerical guard of EmbeddingPack removes them)

@@ -49,6 +49,7 @@ class EmbWeights(C.Structure):
         ("blk_w3", c_fp * PA_MAX_RES_BLOCKS), ("blk_shift3", c_fp * PA_MAX_RES_BLOCKS),
         ("seg1_w", c_fp), ("seg1_b", c_fp),
         ("blk_v1", c_fp * PA_MAX_RES_BLOCKS), ("blk_v2", c_fp * PA_MAX_RES_BLOCKS),
+        ("fb_center_kernel", C.c_int32),
     ]
 
 
@@ -177,6 +178,7 @@ _OPTIONAL: list[tuple] = [
                        c_fp], C.c_int),
     ("pa_fbank", [c_fp, C.c_long, C.c_long, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                   C.c_int, c_fp, C.c_int, c_fp], C.c_int),
+    ("pa_fbank_center_span", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp], C.c_int),
     ("pa_resnet_stem", [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp], C.c_int),
     ("pa_conv3x3", [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int,
                     C.c_int, c_fp], C.c_int),

@@ -13,6 +13,7 @@ import os
 import pickle
 import sys
 import types
+import warnings
 from dataclasses import dataclass
 from enum import Enum
 from functools import cached_property
@@ -310,12 +311,31 @@ class Model:
         klass = {"PyanNet": PyanNet, "SSeRiouSS": SSeRiouSS, "WeSpeakerResNet34": WeSpeakerResNet34,
                  "WeSpeakerResNet152": WeSpeakerResNet152, "WeSpeakerResNet221": WeSpeakerResNet221,
                  "WeSpeakerResNet293": WeSpeakerResNet293, "XVectorSincNet": XVectorSincNet}.get(arch)
+        # a user's own class (the reference imports `architecture.module` and takes `architecture.class` from it,
+        # core/model.py:609-613): its counterpart registered with `register_architecture`
+        module = ckpt["pyannote.audio"]["architecture"].get("module", "")
+        klass = _USER_ARCHITECTURES.get((module, arch), klass)
         if klass is None:
             raise NotImplementedError(
                 f"architecture {arch!r} is outside the accelerated hot path (PyanNet, SSeRiouSS, "
                 "WeSpeakerResNet34/152/221/293, XVectorSincNet)")
         return klass(ckpt["state_dict"], dict(ckpt.get("hyper_parameters", {})),
                      ckpt["pyannote.audio"]["specifications"])
+
+
+_USER_ARCHITECTURES: dict = {}
+
+
+def register_architecture(klass) -> type:
+    """Make `Model.from_pretrained` build `klass` for checkpoints whose architecture is `klass.ARCHITECTURE` =
+    (module, class) of a user's model class in the reference (which finds it by importing that module,
+    core/model.py:609-613).  Usable as a decorator.  Example: a reference subclass of `BaseWeSpeakerResNet` that
+    forwards `fbank_centering_span` <-> a subclass of `WeSpeakerResNet34` here with that key added to `INIT_KEYS`."""
+    module, name = klass.ARCHITECTURE
+    if not module or not name:
+        raise ValueError("ARCHITECTURE = (module, class) of the reference class is required")
+    _USER_ARCHITECTURES[(module, name)] = klass
+    return klass
 
 
 class PyanNet(Model):
@@ -392,9 +412,85 @@ class SSeRiouSS(PyanNet):
 
 
 class WeSpeakerResNet34(Model):
-    """models/embedding/wespeaker/__init__.py:346-372 over the HIP embedding engine."""
+    """models/embedding/wespeaker/__init__.py:346-372 over the HIP embedding engine.
+
+    Every WeSpeaker checkpoint of the reference carries the arguments of its kaldi fbank front end as
+    hyper-parameters (`BaseWeSpeakerResNet.__init__` saves eleven of them, wespeaker/__init__.py:56-85).  Two rules, both
+    the reference's:
+
+    * WHICH of them count.  `Model.from_pretrained` rebuilds the model through Lightning's `load_from_checkpoint`
+      (core/model.py:620-626), which passes the saved hyper-parameters to `cls.__init__` FILTERED BY ITS SIGNATURE
+      (lightning 2.x `core/saving.py::_load_state`: "filter kwargs according to class init unless it allows
+      unspecified arguments via kwargs").  The four stock classes take sample_rate, num_channels, num_mel_bins,
+      frame_length, frame_shift, dither, window_type, use_energy (:346-372, :375-470) -- NOT round_to_power_of_two,
+      snip_edges or fbank_centering_span, which therefore always have their defaults (True, True, None) in the
+      reference whatever the file says.  `INIT_KEYS` mirrors that; a dropped key that differs from its default is
+      reported with a warning, and the default is used -- as in the reference.  A user class of the reference that
+      forwards more of them to `BaseWeSpeakerResNet` has its counterpart here: subclass, extend `INIT_KEYS`, name the
+      reference class in `ARCHITECTURE`, `register_architecture`.
+    * WHAT the front end can do.  csrc/emb_fbank.hip is built for the values every published checkpoint has -- 16 kHz,
+      mono, 80 mel bins, 25 ms / 10 ms hamming frames, no energy, no dither, snip_edges, power-of-two FFT; a
+      hyper-parameter that COUNTS and says anything else is refused at load time (`NotImplementedError`): computing
+      something else without a word would be worse.  `fbank_centering_span` (running instead of global mean
+      subtraction, :137-157) is implemented (`pa_fbank_center_span`)."""
 
     ARCHITECTURE = ("pyannote.audio.models.embedding.wespeaker", "WeSpeakerResNet34")
+
+    #: the hyper-parameters the reference class's __init__ takes (wespeaker/__init__.py:346-372): the others are dropped
+    #: by the reference's loader
+    INIT_KEYS = ("sample_rate", "num_channels", "num_mel_bins", "frame_length", "frame_shift", "dither",
+                 "window_type", "use_energy")
+    #: hyper-parameter -> the one value the HIP fbank kernel is built for (= the reference's defaults, :56-71)
+    FBANK_BUILT_FOR = {"sample_rate": 16000, "num_channels": 1, "num_mel_bins": 80, "frame_length": 25.0,
+                       "frame_shift": 10.0, "round_to_power_of_two": True, "snip_edges": True, "dither": 0.0,
+                       "window_type": "hamming", "use_energy": False}
+
+    @staticmethod
+    def _same(got, built) -> bool:
+        if isinstance(built, bool):
+            return isinstance(got, (bool, int)) and bool(got) == built
+        if isinstance(built, str):
+            return got == built
+        return isinstance(got, (int, float)) and not isinstance(got, bool) and float(got) == float(built)
+
+    def __init__(self, state_dict: dict, hparams: dict, specifications: Specifications):
+        defaults = dict(self.FBANK_BUILT_FOR, fbank_centering_span=None)
+        counted = dict(hparams)
+        for key, default in defaults.items():
+            if key in counted and key not in self.INIT_KEYS:
+                got = counted.pop(key)
+                differs = (got is not None) if default is None else not self._same(got, default)
+                if differs:
+                    warnings.warn(
+                        f"{type(self).__name__}: the checkpoint says {key} = {got!r}, but "
+                        f"{self.ARCHITECTURE[1]}.__init__ of the reference does not take {key} and its loader drops "
+                        f"it (Lightning filters hyper-parameters by the signature): {key} = {default!r} is used, as "
+                        "in the reference")
+        super().__init__(state_dict, counted, specifications)
+        for key, built in self.FBANK_BUILT_FOR.items():
+            got = self.hparams.get(key, built)
+            if not self._same(got, built):
+                raise NotImplementedError(
+                    f"{type(self).__name__}: hyper-parameter {key} = {got!r}, but the HIP fbank front end is built for "
+                    f"{key} = {built!r} only (wespeaker/__init__.py:56-99); refusing to load a checkpoint whose "
+                    "features would silently differ")
+        span = self.hparams.get("fbank_centering_span", None)
+        if span is not None and not (isinstance(span, (int, float)) and not isinstance(span, bool) and span > 0):
+            raise ValueError(f"fbank_centering_span must be None or a positive number of seconds, got {span!r}")
+
+    @property
+    def fbank_center_kernel(self) -> int:
+        """0 = the mean over all frames is subtracted (`fbank_centering_span=None`); otherwise the ODD number of
+        frames of the running mean, F.avg_pool1d(kernel 2 (k // 2) + 1, stride 1, padding k // 2,
+        count_include_pad=False) with k = frames of `fbank_centering_span` seconds (wespeaker/__init__.py:141-157)"""
+        span = self.hparams.get("fbank_centering_span", None)
+        if span is None:
+            return 0
+        sr = int(self.hparams.get("sample_rate", 16000))
+        window = int(sr * float(self.hparams.get("frame_length", 25.0)) * 0.001)
+        step = int(sr * float(self.hparams.get("frame_shift", 10.0)) * 0.001)
+        k = multi_conv_num_frames(int(span * sr), [window], [step], [0], [1])
+        return 2 * (max(k, 0) // 2) + 1
 
     @property
     def dimension(self) -> int:
@@ -446,8 +542,8 @@ class WeSpeakerResNet34(Model):
     def _build_engine(self, device):
         from .embedding import EmbeddingEngine
         from .weights import EmbeddingPack
-        return EmbeddingEngine(EmbeddingPack(self._state_dict, device,
-                                             sample_rate=self.audio.sample_rate))
+        return EmbeddingEngine(EmbeddingPack(self._state_dict, device, sample_rate=self.audio.sample_rate,
+                                             center_kernel=self.fbank_center_kernel))
 
     def __call__(self, waveforms: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.engine.forward(waveforms, weights)

@@ -572,7 +572,7 @@ class EmbeddingPack:
 
     def __init__(self, state_dict: dict, device: torch.device, num_blocks=None,
                  num_mel: int = 80, sample_rate: int = 16000, winograd: Optional[bool] = None,
-                 guard: Optional[bool] = None):
+                 guard: Optional[bool] = None, center_kernel: int = 0):
         if winograd is None:
             winograd = os.environ.get("PA_WINOGRAD", "1") != "0"
         self.winograd = winograd
@@ -585,6 +585,10 @@ class EmbeddingPack:
         self._keep: list[torch.Tensor] = []
         w = ffi.EmbWeights()
         w.num_mel, w.num_layers = num_mel, 4
+        # 0: global mean subtraction; odd K: running mean of K frames (model.WeSpeakerResNet34.fbank_center_kernel)
+        if center_kernel < 0 or (center_kernel and center_kernel % 2 == 0):
+            raise ValueError(f"center_kernel must be 0 or odd, got {center_kernel}")
+        w.fb_center_kernel = int(center_kernel)
         # architecture from the keys: Bottleneck blocks have a conv3 (resnet.py:148-212); block counts =
         # highest block index per layer (ResNet34 3,4,6,3 / 152: 3,8,36,3 / 221: 6,16,48,3 / 293: 10,20,64,3)
         self.bottleneck = "resnet.layer1.0.conv3.weight" in sd

@@ -102,6 +102,13 @@ def _lightning_standins() -> dict:
             ckpt = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
             hparams = dict(ckpt.get("hyper_parameters", {}))
             hparams.update(kwargs)
+            # lightning 2.x core/saving.py::_load_state: "filter kwargs according to class init unless it allows
+            # unspecified arguments via kwargs" -- a saved hyper-parameter that cls.__init__ does not take is dropped
+            # (the eleven fbank hyper-parameters BaseWeSpeakerResNet saves vs the eight WeSpeakerResNet34 takes)
+            import inspect
+            params = inspect.signature(cls.__init__).parameters
+            if not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values()):
+                hparams = {k: v for k, v in hparams.items() if k in params}
             model = cls(**hparams)
             model.on_load_checkpoint(ckpt)
             model.load_state_dict(ckpt["state_dict"], strict=strict)

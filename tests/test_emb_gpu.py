@@ -65,6 +65,67 @@ def test_fbank(emb, gpu_device):
     assert e < 2e-3
 
 
+@pytest.mark.parametrize("T,nmel,K", [(298, 80, 39), (998, 80, 299), (298, 80, 1), (248, 80, 2999), (77, 23, 5),
+                                      (1201, 80, 301)])
+def test_fbank_center_span_kernel(gpu_device, T, nmel, K):
+    """pa_fbank_center_span == x - F.avg_pool1d(x, K, 1, K // 2, count_include_pad=False) (wespeaker/__init__.py:
+    151-157): frames near both ends (windows clipped to the chunk), windows longer than the chunk, several frame
+    tiles and mel groups.  Same float32 sums in the same order: the bound is a few ulp of the features."""
+    import pyannote_audio_amd.ffi as ffi
+    lib = ffi.load()
+    g = torch.Generator().manual_seed(T + K)
+    x = 4.0 * torch.randn(3, T, nmel, generator=g) - 9.0
+    want = x - F.avg_pool1d(x.transpose(1, 2), kernel_size=K, stride=1, padding=K // 2,
+                            count_include_pad=False).transpose(1, 2)
+    xd = x.to(gpu_device)
+    out = torch.full_like(xd, float("nan"))
+    ffi.check(lib.pa_fbank_center_span(ffi.ptr(xd), 3, T, nmel, K, ffi.ptr(out), ffi.stream()), "center_span")
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), x)                        # out of place
+    err = (out.cpu() - want).abs().max().item()
+    report(f"fbank_center_span_T{T}_K{K}", out, want)
+    assert err <= 4e-6, err                                # |x| ~ 20: one ulp is 1.9e-6
+    # refusals: even windows, in place
+    assert lib.pa_fbank_center_span(ffi.ptr(xd), 3, T, nmel, 4, ffi.ptr(out), ffi.stream()) != 0
+    assert lib.pa_fbank_center_span(ffi.ptr(xd), 3, T, nmel, K, ffi.ptr(xd), ffi.stream()) != 0
+
+
+@pytest.mark.parametrize("span", [0.4, 3.0])
+def test_emb_forward_with_centering_span(gpu_device, span, tmp_path):
+    """a checkpoint of a user class that forwards `fbank_centering_span` (wespeaker/__init__.py:137-157), loaded through
+    the registered counterpart: embeddings against the oracle with the same span, north-star tolerance"""
+    import pyannote_audio_amd as pa
+    from pyannote_audio_amd import model as pm
+    from oracle import seeded_wespeaker
+    from conftest import WESPEAKER_HPARAMS
+
+    @pm.register_architecture
+    class CentredResNet34(pm.WeSpeakerResNet34):
+        ARCHITECTURE = ("my_project.models", "CentredResNet34")
+        INIT_KEYS = pm.WeSpeakerResNet34.INIT_KEYS + ("fbank_centering_span",)
+
+    try:
+        oracle_model = seeded_wespeaker(seed=4321)
+        oracle_model.fbank_centering_span = span
+        path = str(tmp_path / "centred.bin")
+        pm.save_checkpoint(path, oracle_model.state_dict(), dict(WESPEAKER_HPARAMS, fbank_centering_span=span),
+                           CentredResNet34.ARCHITECTURE, pm.embedding_specifications())
+        model = pa.Model.from_pretrained(path).to(gpu_device)
+        assert model.fbank_center_kernel == (39 if span == 0.4 else 299)
+        x = _wave(3, 48000, seed=7)
+        g = torch.Generator().manual_seed(4)
+        masks = (torch.rand(3, 3, 173, generator=g) < 0.7).float()
+        with torch.inference_mode():
+            ref = oracle_model(x, weights=masks)
+            plain = seeded_wespeaker(seed=4321)(x, weights=masks)
+        out = model(x.to(gpu_device), masks.to(gpu_device))
+        torch.cuda.synchronize()
+        assert north_star_ratio(f"emb_center_span_{span}", out, ref) <= 1.0
+        assert north_star_ratio(f"emb_center_span_{span}_vs_global_mean", out, plain, ) > 1.0   # (it is not a no-op)
+    finally:
+        pm._USER_ARCHITECTURES.pop(CentredResNet34.ARCHITECTURE, None)
+
+
 def test_conv3x3_configs(gpu_device):
     import pyannote_audio_amd.ffi as ffi
     lib = ffi.load()

@@ -97,6 +97,65 @@ def test_reference_loader_reads_product_checkpoints(ref, model_dir, models):
     assert seg_r.num_frames(160000) == 589 and seg_r.num_frames(80000) == 293
 
 
+@pytest.mark.parametrize("span", [None, 0.4, 1.0, 3.0, 30.0])
+def test_reference_compute_fbank_centering_span_equals_oracle(ref, span):
+    """wespeaker/__init__.py:113-157 executed from the reference's file: global mean (`None`) and the running mean of
+    `fbank_centering_span` seconds (a window shorter than the chunk, about the chunk, far longer than the chunk) --
+    the oracle's restatement is bit-identical, and so is the embedding of the whole model.  The stock classes do not
+    take `fbank_centering_span` (:346-372): the reference-side model is what a user of the reference would write, a
+    subclass that forwards it to `BaseWeSpeakerResNet`."""
+    import oracle.models as om
+    wespeaker = ref["r"].load("pyannote.audio.models.embedding.wespeaker")
+    resnet = ref["r"].load("pyannote.audio.models.embedding.wespeaker.resnet")
+
+    class Centred(wespeaker.BaseWeSpeakerResNet):
+        def __init__(self, fbank_centering_span=None):
+            super().__init__(fbank_centering_span=fbank_centering_span)
+            self.resnet = resnet.ResNet34(80, 256, pooling_func="TSTP", two_emb_layer=False)
+
+    torch.manual_seed(21)
+    theirs = Centred(fbank_centering_span=span).eval()
+    assert theirs.hparams.fbank_centering_span == span and theirs.hparams.window_type == "hamming"
+    ours = om.WeSpeakerResNet34(fbank_centering_span=span).eval()
+    ours.load_state_dict(theirs.state_dict())
+    g = torch.Generator().manual_seed(9)
+    wav = (0.1 * torch.randn(2, 1, 40000, generator=g)).clamp(-1, 1)
+    with torch.inference_mode():
+        want = theirs.compute_fbank(wav)
+        got = ours.compute_fbank(wav)
+        assert want.shape == (2, 248, 80) and torch.equal(got, want)
+        assert torch.equal(ours(wav), theirs(wav))
+        plain = om.WeSpeakerResNet34().compute_fbank(wav)
+    # (a window that covers the chunk from every frame is the global mean up to the order of the float32 sums)
+    assert (span is None) == torch.equal(plain, want)
+    if span == 30.0:
+        assert torch.allclose(plain, want, atol=1e-4)
+
+
+def test_reference_loader_drops_hyper_parameters_its_classes_do_not_take(ref, model_dir, tmp_path):
+    """A WeSpeakerResNet34 checkpoint that SAYS fbank_centering_span = 3.0 / snip_edges = False: the reference's class
+    does not take either (wespeaker/__init__.py:346-372), its loader drops them (Lightning's `_load_state`, restated in
+    tests/refharness.py -- Lightning itself is absent: unpinned) and computes the defaults.  The product does the same
+    and says so; a hyper-parameter that counts and that the HIP front end is not built for is refused."""
+    import warnings
+    import pyannote_audio_amd as pa
+    from pyannote_audio_amd.model import load_checkpoint, save_checkpoint
+    src = os.path.join(model_dir, "embedding", "pytorch_model.bin")
+    ckpt = load_checkpoint(src)
+    odd = dict(ckpt["hyper_parameters"], fbank_centering_span=3.0, snip_edges=False)
+    path = str(tmp_path / "odd.bin")
+    save_checkpoint(path, ckpt["state_dict"], odd, ("pyannote.audio.models.embedding.wespeaker", "WeSpeakerResNet34"),
+                    ckpt["pyannote.audio"]["specifications"])
+    theirs = ref["Model"].from_pretrained(path)
+    assert theirs.hparams.fbank_centering_span is None and theirs.hparams.snip_edges is True
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        ours = pa.Model.from_pretrained(path)
+    assert ours.fbank_center_kernel == 0
+    text = " ".join(str(w.message) for w in seen)
+    assert "fbank_centering_span = 3.0" in text and "snip_edges = False" in text and "as in the reference" in text
+
+
 def test_reference_inference_on_sample_wav(ref, model_dir, models):
     """BASELINE configs[0] on the reference's own `Inference` (core/inference.py:217-373) over its own
     30 s fixture: (21, 589, 3) hard multilabel chunks, equal to oracle.pipeline.slide."""
