@@ -16,6 +16,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // D: lane l holds column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15.
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// launchers shared between translation units of the library that are NOT part of the C ABI (include/pyannote_amd.h
+// declares every exported symbol; tests/test_capi.py checks both directions)
+#define PA_INTERNAL __attribute__((visibility("hidden")))
+
 namespace pa {
 
 void set_error(const char* fmt, ...);

@@ -11,19 +11,21 @@ namespace pa {
 void set_error(const char* fmt, ...);
 }
 
+// (internal launchers of w2v.hip: not part of the C ABI, hidden in the shared library -- csrc/common.h)
+#define PA_INTERNAL __attribute__((visibility("hidden")))
 extern "C" {
-int pa_w2v_conv0(const float* wav, long wav_len, long chunk_stride, int B, int N, int T, int P, int C, int K0,
+PA_INTERNAL int pa_w2v_conv0(const float* wav, long wav_len, long chunk_stride, int B, int N, int T, int P, int C, int K0,
                  int S0, const float* w, const float* bias, float* out, void* stream);
-int pa_w2v_group_norm_gelu(float* x, int B, int T, int P, int C, const float* gamma, const float* beta,
+PA_INTERNAL int pa_w2v_group_norm_gelu(float* x, int B, int T, int P, int C, const float* gamma, const float* beta,
                            float* mean_scratch, float* rstd_scratch, void* stream);
-int pa_w2v_layernorm(const float* in, float* out, long rows, int C, const float* gamma, const float* beta,
+PA_INTERNAL int pa_w2v_layernorm(const float* in, float* out, long rows, int C, const float* gamma, const float* beta,
                      int gelu, void* stream);
-int pa_w2v_posconv(const float* x, int B, int T, int P, int D, int groups, int KW, const float* w3,
+PA_INTERNAL int pa_w2v_posconv(const float* x, int B, int T, int P, int D, int groups, int KW, const float* w3,
                    const float* bias, float* out, void* stream);
-int pa_w2v_softmax(float* S, int B, int H, int T, int Tp, float scale, const float* bias, const float* xin, int P,
+PA_INTERNAL int pa_w2v_softmax(float* S, int B, int H, int T, int Tp, float scale, const float* bias, const float* xin, int P,
                    int D, const float* gate_w, const float* gate_b, const float* gate_const, void* stream);
-int pa_w2v_axpy(float* acc, const float* x, float w, long n, int first, void* stream);
-int pa_w2v_to_tiles(const float* x, int B, int T, int P, int D, float* out, void* stream);
+PA_INTERNAL int pa_w2v_axpy(float* acc, const float* x, float w, long n, int first, void* stream);
+PA_INTERNAL int pa_w2v_to_tiles(const float* x, int B, int T, int P, int D, float* out, void* stream);
 int pa_gemm_tn_batched(const float* A, int lda, long sAo, long sAi, const float* W, int ldw, long sWo, long sWi,
                        const float* bias, float* C, long ldc, long sCo, long sCi, int M, int N, int K,
                        int outer, int inner, int act, void* stream);

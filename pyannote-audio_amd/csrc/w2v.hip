@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_w2v_to_tiles(const float* __restrict__ 
 
 extern "C" {
 
-int pa_w2v_conv0(const float* wav, long wav_len, long chunk_stride, int B, int N, int T, int P, int C, int K0,
+PA_INTERNAL int pa_w2v_conv0(const float* wav, long wav_len, long chunk_stride, int B, int N, int T, int P, int C, int K0,
                  int S0, const float* w, const float* bias, float* out, void* stream) {
   if (B <= 0) return 0;
   PA_REQUIRE(K0 >= 1 && K0 <= 16 && S0 >= 1 && S0 <= 16, "pa_w2v_conv0: kernel and stride <= 16 required");
@@ -255,7 +255,7 @@ int pa_w2v_conv0(const float* wav, long wav_len, long chunk_stride, int B, int N
   return 0;
 }
 
-int pa_w2v_group_norm_gelu(float* x, int B, int T, int P, int C, const float* gamma, const float* beta,
+PA_INTERNAL int pa_w2v_group_norm_gelu(float* x, int B, int T, int P, int C, const float* gamma, const float* beta,
                            float* mean_scratch, float* rstd_scratch, void* stream) {
   if (B <= 0) return 0;
   pa::ProfScope prof("k_w2v_group_norm", stream, 8.0 * B * T * C, 16.0 * B * T * C);
@@ -267,7 +267,7 @@ int pa_w2v_group_norm_gelu(float* x, int B, int T, int P, int C, const float* ga
   return 0;
 }
 
-int pa_w2v_layernorm(const float* in, float* out, long rows, int C, const float* gamma, const float* beta,
+PA_INTERNAL int pa_w2v_layernorm(const float* in, float* out, long rows, int C, const float* gamma, const float* beta,
                      int gelu, void* stream) {
   if (rows <= 0) return 0;
   PA_REQUIRE(C >= 1 && C <= 1024, "pa_w2v_layernorm: C <= 1024 required (got %d)", C);
@@ -282,7 +282,7 @@ int pa_w2v_layernorm(const float* in, float* out, long rows, int C, const float*
   return 0;
 }
 
-int pa_w2v_posconv(const float* x, int B, int T, int P, int D, int groups, int KW, const float* w3,
+PA_INTERNAL int pa_w2v_posconv(const float* x, int B, int T, int P, int D, int groups, int KW, const float* w3,
                    const float* bias, float* out, void* stream) {
   if (B <= 0) return 0;
   const int CG = D / groups;
@@ -295,7 +295,7 @@ int pa_w2v_posconv(const float* x, int B, int T, int P, int D, int groups, int K
   return 0;
 }
 
-int pa_w2v_softmax(float* S, int B, int H, int T, int Tp, float scale, const float* bias, const float* xin, int P,
+PA_INTERNAL int pa_w2v_softmax(float* S, int B, int H, int T, int Tp, float scale, const float* bias, const float* xin, int P,
                    int D, const float* gate_w, const float* gate_b, const float* gate_const, void* stream) {
   if (B <= 0) return 0;
   PA_REQUIRE(D % H == 0 && D / H <= 128, "pa_w2v_softmax: head dimension <= 128 required");
@@ -307,7 +307,7 @@ int pa_w2v_softmax(float* S, int B, int H, int T, int Tp, float scale, const flo
   return 0;
 }
 
-int pa_w2v_axpy(float* acc, const float* x, float w, long n, int first, void* stream) {
+PA_INTERNAL int pa_w2v_axpy(float* acc, const float* x, float w, long n, int first, void* stream) {
   if (n <= 0) return 0;
   PA_REQUIRE(n % 4 == 0, "pa_w2v_axpy: n %% 4 == 0 required");
   pa::ProfScope prof("k_w2v_axpy", stream, 2.0 * n, 12.0 * n);
@@ -317,7 +317,7 @@ int pa_w2v_axpy(float* acc, const float* x, float w, long n, int first, void* st
   return 0;
 }
 
-int pa_w2v_to_tiles(const float* x, int B, int T, int P, int D, float* out, void* stream) {
+PA_INTERNAL int pa_w2v_to_tiles(const float* x, int B, int T, int P, int D, float* out, void* stream) {
   if (B <= 0) return 0;
   const int ntiles = (B + 15) / 16;
   pa::ProfScope prof("k_w2v_to_tiles", stream, 0.0, 8.0 * B * T * D);

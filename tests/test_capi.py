@@ -24,6 +24,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, f"declared in the header but not exported: {missing}"
     assert lib.pa_version() >= 100
     assert isinstance(lib.pa_last_error(), bytes)
+    # ... and the other way round: nothing named pa_* is exported that the header does not declare (internal launchers
+    # shared between translation units are hidden: csrc/common.h PA_INTERNAL)
+    import subprocess
+    from pyannote_audio_amd._build import LIB_PATH
+    out = subprocess.run(["nm", "-D", "--defined-only", str(LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("pa_") and " T " in ln}
+    assert exported == set(names), f"exported but undeclared: {sorted(exported - set(names))}"
 
 
 def test_frame_arithmetic_entry_points():

@@ -91,6 +91,28 @@ def test_full_pipeline_matches_oracle(pipeline_dir, synthetic_models, gpu_device
     assert "SPEAKER synth 1" in ann.to_rttm()
 
 
+def test_verify_checkpoint_tool(pipeline_dir, gpu_device, tmp_path):
+    """tools/verify_checkpoint.py end to end on the seeded checkpoints and the reference's 30-s fixture: every row of
+    its table passes (what the owner of real weights runs on theirs)"""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("verify_checkpoint", os.path.join(root, "tools", "verify_checkpoint.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    out_json = str(tmp_path / "report.json")
+    rc = tool.main([pipeline_dir, os.path.join(root, "tests", "golden", "sample.wav"), "--max-seconds", "22",
+                    "--chunks", "3", "--json", out_json])
+    rep = json.load(open(out_json))
+    with open("gpurun_out/parity.log", "a") as fp:
+        for r in rep["rows"]:
+            fp.write(f"verify_checkpoint: {r['stage']}: {r['what']}: {r['value']} pass={r['pass']}\n")
+    assert rc == 0 and rep["ok"]
+    verdicts = [r for r in rep["rows"] if r["pass"] is not None]
+    assert len(verdicts) >= 6 and all(r["pass"] for r in verdicts)
+
+
 def test_silence_returns_empty(pipeline_dir, gpu_device):
     """count == 0 everywhere -> early exit with empty annotations (speaker_diarization.py:617-629)."""
     import pyannote_audio_amd as pa

@@ -1,6 +1,8 @@
 """Build A/B variants of one kernel file next to the product library (development aid): the variant's
-object replaces the product object at link time.  usage: python tools/build_variants.py
-Variants land in pyannote-audio_amd/build/variants/libpa_<tag>.so; select one with PA_LIB=<path>."""
+object replaces the product object at link time.  usage: python tools/build_variants.py <tag> [<tag> ...] | --all | --list
+Variants land in pyannote-audio_amd/build/variants/libpa_<tag>.so; select one with PA_LIB=<path>.  Only the tags named
+are built, and the variants of earlier calls are REMOVED first: every .so under the repository travels to the GPU box
+with each gpurun call (round 5 shipped 47 MB of them every time)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,11 +35,25 @@ VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or
 
 
 def main():
+    import shutil
+    args = sys.argv[1:]
+    if "--list" in args:
+        for tag, (src, flags, rev) in VARIANTS.items():
+            print(f"{tag:18s} {src:22s} {flags} {rev or ''}")
+        return
+    tags = list(VARIANTS) if "--all" in args else args
+    unknown = [t for t in tags if t not in VARIANTS]
+    if unknown:
+        raise SystemExit(f"unknown variant(s) {unknown}; --list shows them")
     _build.build_library()
     out = _build.PKG_DIR / "build" / "variants"
+    shutil.rmtree(out, ignore_errors=True)
+    if not tags:
+        print("no variant requested: pyannote-audio_amd/build/variants/ removed")
+        return
     out.mkdir(parents=True, exist_ok=True)
     objs = {p.name: p for p in (_build.PKG_DIR / "build").glob("*.o")}
-    for tag, (src, flags, rev) in VARIANTS.items():
+    for tag, (src, flags, rev) in ((t, VARIANTS[t]) for t in tags):
         path = _build.CSRC / src
         if rev:
             text = subprocess.check_output(["git", "show", f"{rev}:pyannote-audio_amd/csrc/{src}"], cwd=ROOT)

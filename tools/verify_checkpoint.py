@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""verify_checkpoint.py -- the north-star parity table for YOUR weights.
+
+    python tools/verify_checkpoint.py <pipeline directory | config.yaml> <audio.wav> [--max-seconds 60]
+                                      [--chunks 12] [--oracle-only] [--json report.json]
+
+Every parity test of this repository runs on seeded synthetic checkpoints (there is no network in the build container:
+SURVEY.md section 8c asks to "verify against a real checkpoint when one is available").  This tool is that check for the
+owner of real weights -- e.g. a local copy of pyannote/speaker-diarization-3.1 with pyannote/segmentation-3.0 and
+pyannote/wespeaker-voxceleb-resnet34-LM in the directory layout `Pipeline.from_pretrained` reads (config.yaml +
+$model/segmentation/pytorch_model.bin + $model/embedding/pytorch_model.bin).  It runs
+
+  * the HIP path (`pyannote_audio_amd`, libpyannote_amd.so on cuda:0), and
+  * a torch-CPU evaluation of the SAME state-dicts (the oracle modules of oracle/, which restate the reference's
+    models and pipeline and are pinned to the reference's own code by tests/test_reference_pipeline.py; float32 as the
+    reference computes, and float64 to show how far float32 itself is from the exact value on this audio)
+
+on the same audio and prints, stage by stage, max |d| / (1e-5 + 1e-4 |ref|) (BASELINE.json north star: <= 1 passes) for the
+segmentation scores and the embeddings, the hard decisions that differ (and how many of them lie outside a 1e-4 gap
+between the two best classes), and whether speaker counts, cluster labels and output turns are identical.
+
+The tool may import `oracle`; the product does not.  `--oracle-only` (no GPU needed) stops after the CPU evaluation:
+it checks that the checkpoints load into the reference-shaped modules (strict state-dict match) and prints their side
+of the table."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+RTOL, ATOL, GAP = 1e-4, 1e-5, 1e-4
+
+
+def ratio(got, want) -> float:
+    got = torch.as_tensor(got).double()
+    want = torch.as_tensor(want).double()
+    both_nan = torch.isnan(got) & torch.isnan(want)
+    d = torch.where(both_nan, torch.zeros_like(got), (got - want).abs() / (ATOL + RTOL * want.abs()))
+    return float("inf") if torch.isnan(d).any() else d.max().item()
+
+
+def oracle_from_checkpoint(path: str):
+    """the checkpoint's state-dict in the oracle's restatement of the class it names (strict load)"""
+    import oracle.models as om
+    from pyannote_audio_amd.model import load_checkpoint
+    ckpt = load_checkpoint(path)
+    arch = ckpt["pyannote.audio"]["architecture"]["class"]
+    hp = dict(ckpt.get("hyper_parameters", {}))
+    spec = ckpt["pyannote.audio"]["specifications"]
+    if arch == "PyanNet":
+        powerset = bool(spec.powerset)
+        num_classes = spec.num_powerset_classes if powerset else len(spec.classes)
+        model = om.PyanNet(num_classes, sincnet=hp.get("sincnet"), lstm=hp.get("lstm"), linear=hp.get("linear"),
+                           sample_rate=int(hp.get("sample_rate", 16000)), powerset=powerset)
+    elif arch.startswith("WeSpeakerResNet"):
+        blocks = {"34": (3, 4, 6, 3), "152": (3, 8, 36, 3), "221": (6, 16, 48, 3), "293": (10, 20, 64, 3)}[arch[15:]]
+        model = om.WeSpeakerResNet34(num_blocks=blocks, block=None if arch.endswith("34") else om.Bottleneck)
+    else:
+        raise SystemExit(f"verify_checkpoint: no CPU restatement wired for architecture {arch!r} "
+                         "(PyanNet and WeSpeakerResNet34/152/221/293 are)")
+    model.load_state_dict({k: v for k, v in ckpt["state_dict"].items()}, strict=True)
+    return model.eval(), arch, spec
+
+
+def resolve(config_or_dir: str):
+    """-> (directory, config dict, segmentation checkpoint, embedding checkpoint)"""
+    import yaml
+    cfg_path = os.path.join(config_or_dir, "config.yaml") if os.path.isdir(config_or_dir) else config_or_dir
+    root = os.path.dirname(os.path.abspath(cfg_path))
+    with open(cfg_path) as fp:
+        config = yaml.safe_load(fp)
+    params = config["pipeline"]["params"]
+
+    def ckpt_of(entry):
+        if isinstance(entry, dict):
+            entry = os.path.join(entry.get("checkpoint", ""), entry.get("subfolder", "") or "")
+        path = str(entry).replace("$model", root)
+        return os.path.join(path, "pytorch_model.bin") if os.path.isdir(path) else path
+
+    return root, config, ckpt_of(params["segmentation"]), ckpt_of(params["embedding"])
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("pipeline", help="directory with config.yaml (or the config.yaml itself)")
+    ap.add_argument("audio", help="a PCM WAV file")
+    ap.add_argument("--max-seconds", type=float, default=60.0, help="evaluate the first N seconds (the CPU side is slow)")
+    ap.add_argument("--chunks", type=int, default=12, help="chunks of the model-level comparisons")
+    ap.add_argument("--oracle-only", action="store_true", help="CPU side only (no GPU needed)")
+    ap.add_argument("--json", default=None, help="also write the report as JSON")
+    args = ap.parse_args(argv)
+
+    from oracle import pipeline as op
+    from pyannote_audio_amd.audio import Audio
+    root, config, seg_path, emb_path = resolve(args.pipeline)
+    name = config["pipeline"]["name"].rsplit(".", 1)[-1]
+    pparams = config["pipeline"]["params"]
+    if name != "SpeakerDiarization" or pparams.get("clustering", "VBxClustering") != "AgglomerativeClustering":
+        raise SystemExit("verify_checkpoint: the end-to-end leg restates SpeakerDiarization with AgglomerativeClustering "
+                         f"(speaker-diarization-3.1); this config is {name} / {pparams.get('clustering')}")
+    seg_o, seg_arch, seg_spec = oracle_from_checkpoint(seg_path)
+    emb_o, emb_arch, _ = oracle_from_checkpoint(emb_path)
+    print(f"segmentation: {seg_arch} <- {seg_path}\nembedding:    {emb_arch} <- {emb_path}   (strict state-dict match: ok)")
+    wav, sr = Audio(16000, mono="downmix")(args.audio)
+    wav = wav[:, : int(args.max_seconds * sr)]
+    seconds = wav.shape[1] / sr
+    duration = float(seg_spec.duration)
+    window = int(round(duration * sr))
+    if wav.shape[1] < window:
+        raise SystemExit(f"verify_checkpoint: the audio is shorter than one {duration:g}-s chunk")
+    inst = config.get("params", {})
+    cl = inst.get("clustering", {})
+    kw = dict(duration=duration, segmentation_step=float(pparams.get("segmentation_step", 0.1)),
+              exclude_overlap=bool(pparams.get("embedding_exclude_overlap", False)),
+              method=cl.get("method", "centroid"), threshold=cl.get("threshold", 0.7045654963945799),
+              min_cluster_size=cl.get("min_cluster_size", 12),
+              segmentation_threshold=inst.get("segmentation", {}).get("threshold", 0.5))
+    report = {"audio_seconds": seconds, "segmentation": seg_arch, "embedding": emb_arch, "tolerance":
+              {"rtol": RTOL, "atol": ATOL, "hard_decision_gap": GAP}, "rows": []}
+
+    def row(stage, what, value, verdict=None):
+        report["rows"].append({"stage": stage, "what": what, "value": value, "pass": verdict})
+        mark = "" if verdict is None else ("   ok" if verdict else "   FAIL")
+        shown = f"{value:.3f}" if isinstance(value, float) else str(value)
+        print(f"  {stage:14s} {what:66s} {shown:>12s}{mark}", flush=True)
+
+    # ---- model level: the same chunks through both sides
+    starts = np.linspace(0, wav.shape[1] - window, num=min(args.chunks, 1 + (wav.shape[1] - window) // 1600)).astype(int)
+    chunks = torch.stack([wav[:, s:s + window] for s in starts])            # (B, 1, window)
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        seg32 = seg_o(chunks)
+        seg64 = seg_o.double()(chunks.double()).float()
+        seg_o.float()
+        hard32 = seg32.argmax(-1) if getattr(seg_o, "powerset", True) else (seg32 > 0.5)
+        # pooling masks of the embedding comparison: the float32 oracle's own hard decisions, first class that is active
+        act = torch.nn.functional.one_hot(hard32, seg32.shape[-1]).float() if getattr(seg_o, "powerset", True) \
+            else hard32.float()
+        masks = (act[..., 1:2] if act.shape[-1] > 1 else act).transpose(1, 2).contiguous()     # (B, 1, F)
+        masks[masks.sum(dim=(1, 2)) == 0] = 1.0
+        emb32 = emb_o(chunks, weights=masks[:, 0])
+        emb64 = emb_o.double()(chunks.double(), weights=masks[:, 0].double()).float()
+        emb_o.float()
+        cpu_s = time.perf_counter() - t0
+    print(f"\n{len(starts)} chunks of {duration:g} s, model level (CPU float32 + float64: {cpu_s:.1f} s)")
+    row("segmentation", "float32 CPU vs float64 CPU: ratio (what float32 itself costs here)", ratio(seg32, seg64))
+    row("embedding", "float32 CPU vs float64 CPU: ratio", ratio(emb32, emb64))
+
+    gpu = not args.oracle_only
+    if gpu:
+        import pyannote_audio_amd as pa
+        import pyannote_audio_amd.ffi as ffi
+        ffi.require_gpu()
+        device = torch.device("cuda", 0)
+        pipeline = pa.Pipeline.from_pretrained(args.pipeline)
+        pipeline.to(device)
+        seg_m, emb_m = pipeline._segmentation.model, pipeline._embedding.model_
+        got_seg = seg_m(chunks.to(device)).cpu()
+        got_emb = emb_m(chunks.to(device), masks.to(device)).cpu()[:, 0]
+        torch.cuda.synchronize()
+        r32, r64 = ratio(got_seg, seg32), ratio(got_seg, seg64)
+        row("segmentation", "HIP vs float32 CPU: ratio", r32, r32 <= 1.0 or r64 <= max(1.0, ratio(seg32, seg64)))
+        row("segmentation", "HIP vs float64 CPU: ratio (<= the float32 CPU's own, above: as good)", r64)
+        if getattr(seg_o, "powerset", True):
+            got_hard = got_seg.argmax(-1)
+            differ = got_hard != hard32
+            top2 = seg64.topk(2, dim=-1).values
+            unsafe = differ & ((top2[..., 0] - top2[..., 1]) > GAP)
+            row("segmentation", f"hard decisions that differ / outside the {GAP:g} gap (of {differ.numel()})",
+                f"{int(differ.sum())} / {int(unsafe.sum())}", int(unsafe.sum()) == 0)
+        e32, e64 = ratio(got_emb, emb32), ratio(got_emb, emb64)
+        row("embedding", "HIP vs float32 CPU: ratio", e32, e32 <= 1.0 or e64 <= max(1.0, ratio(emb32, emb64)))
+        row("embedding", "HIP vs float64 CPU: ratio", e64)
+
+    # ---- the whole pipeline
+    print(f"\nwhole pipeline on {seconds:.1f} s of audio")
+    t0 = time.perf_counter()
+    want = op.diarize(seg_o, emb_o, wav, sample_rate=sr, **kw)
+    row("pipeline", f"CPU restatement: turns / speakers ({time.perf_counter() - t0:.1f} s)",
+        f"{len(want.diarization)} / {len({l for _, _, l in want.diarization})}")
+    if gpu:
+        seen = {}
+
+        def hook(step, artefact, file=None, total=None, completed=None):
+            if artefact is not None and total is None:
+                seen[step] = np.array(getattr(artefact, "data", artefact), copy=True)
+
+        t0 = time.perf_counter()
+        out = pipeline({"waveform": wav, "sample_rate": sr, "uri": "verify"}, hook=hook)
+        torch.cuda.synchronize()
+        row("pipeline", f"HIP path ({time.perf_counter() - t0:.2f} s, first call: includes set-up)", "ran")
+        mism = int((seen["segmentation"] != want.segmentations).sum())
+        row("pipeline", f"hard segmentation frames that differ (of {want.segmentations.size})", mism, None)
+        same_seg = mism == 0
+        row("pipeline", "speaker counts identical", bool(np.array_equal(seen["speaker_counting"].reshape(-1),
+                                                                         np.asarray(want.count).reshape(-1))),
+            None if not same_seg else bool(np.array_equal(seen["speaker_counting"].reshape(-1),
+                                                          np.asarray(want.count).reshape(-1))))
+        if same_seg:
+            er = ratio(seen["embeddings"], want.embeddings)
+            row("pipeline", "embeddings of all (chunk, speaker) pairs: ratio", er, er <= 1.0)
+        turns = [(s.start, s.end, l) for s, _, l in out.speaker_diarization.itertracks(yield_label=True)]
+        same_turns = turns == want.diarization
+        row("pipeline", "cluster labels -> output turns identical", same_turns, same_turns if same_seg else None)
+        if not same_turns:
+            row("pipeline", "turns HIP / CPU", f"{len(turns)} / {len(want.diarization)}")
+        if not same_seg:
+            print("  (hard decisions differ inside the float32 noise of the scores -- see the gap row above; everything "
+                  "downstream is then compared on different inputs and reported without a verdict)")
+    failed = [r for r in report["rows"] if r["pass"] is False]
+    report["ok"] = not failed
+    print(("\nall checks passed" if not failed else f"\n{len(failed)} check(s) FAILED") +
+          ("" if gpu else " (CPU side only: --oracle-only)"))
+    if args.json:
+        with open(args.json, "w") as fp:
+            json.dump(report, fp, indent=1)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
