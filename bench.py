@@ -607,6 +607,12 @@ def main():
             "roofline_others": others,
             "kernels": kernels,
         }
+        # the numerical guard's decisions (weights.EmbeddingPack): a convolution demoted from F(4x4) to a slower
+        # kernel changes the numbers above -- it has to be visible next to them
+        guard = pipeline._embedding.model_.engine.pack.winograd_guard
+        line["winograd_guard"] = {"convolutions_measured": len(guard),
+                                  "demoted": [f"layer{g['layer']}.{g['block']}.conv{g['conv']} -> {g['path']}"
+                                              for g in guard if g["path"] != ("f4" if g["f4"] is not None else "f2")]}
         if shared_gpu:
             line["functional_check_only"] = f"{world} ranks share cuda:0 over gloo (PA_BENCH_SHARED_GPU=1): not a measurement"
         if joint_info is not None:

@@ -298,6 +298,13 @@ __device__ __forceinline__ void wino_out_offsets(int (&off)[4], const WinoTile& 
 // at 16 l) by LDS-DMA pieces issued in front of the tile's LAST MFMA run, so that their HBM latency hides under
 // that run without holding registers (the kernel has none to spare: a register version spilled 20-30 VGPRs);
 // the second group's loads are issued here and hide under the first group's inverse transform.
+// 16-byte stores of one epilogue per lane: 2 channel groups x the 4 outputs of the F(2x2) tile -- the NEWEST vector
+// memory operations of whoever calls it (k_conv3x3_wino32 counts on that: WINO_EPILOGUE_STORES_LIT in its step wait)
+constexpr int WINO_EPILOGUE_STORES = 2 * 4;
+#define WINO_EPILOGUE_STORES_LIT 8
+static_assert(WINO_EPILOGUE_STORES == WINO_EPILOGUE_STORES_LIT, "the literal of the s_waitcnt string");
+#define WINO_STR2(x) #x
+#define WINO_STR(x) WINO_STR2(x)
 template <bool HAS_R, bool PRE = false, bool PRE0 = false, bool PIN = false>
 __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const WinoTile& q, int H, int W,
                                               int COUT, const float* __restrict__ shift,
@@ -350,6 +357,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x4 (&acc)[16][2], const W
     o4[1] = dd[0] + dd[1] + dd[2];
     o4[2] = vsub(vsub(s[1], s[2], m1), s[3], m1);
     o4[3] = vsub(vsub(dd[1], dd[2], m1), dd[3], m1);
+    static_assert(WINO_EPILOGUE_STORES == 2 * 4, "2 channel groups x 4 stores below");
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const f32x4 vv = __builtin_elementwise_max(o4[e] + sh + rv[cg][e], lo4);
@@ -661,7 +669,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino32(
     // what the barrier needs is this half's patch in LDS.  The epilogue's 8 stores per lane are the NEWEST vector memory
     // operations of a PREPARE step (the patch pieces and the residual loads are older) and complete in order: leaving
     // them in flight across the barrier takes their acknowledgement latency off every step's critical path.
-    if (PA_WINO32_PATCH_FIRST && !PA_WINO32_WAIT_STORES && stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    if (PA_WINO32_PATCH_FIRST && !PA_WINO32_WAIT_STORES && stored)
+      asm volatile("s_waitcnt vmcnt(" WINO_STR(WINO_EPILOGUE_STORES_LIT) ") lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     wino_barrier();
     if (mail[2] == 0 && mail[3] == 0) break;

@@ -209,8 +209,23 @@ __device__ unsigned long long g_w4_stamps[8 * 4 * 64 * 10];
 #endif
 
 constexpr int W4_AGPR_POINTS = 32;   // 256 AccVGPRs; 4 points (32 registers) stay architectural
+// The partial waits of the stage loop count vector-memory operations (they complete in order): the numbers below are
+// what the issue loops and the epilogue are BUILT from, so that a change of either cannot silently turn a wait into a
+// read-before-DMA race.
+constexpr int W4_U_PIECES = Wino4Geom::UINSTR / 4;   // U pieces of a stage per wave: issued BEHIND its patch pieces
+static_assert(W4_U_PIECES == 9 && Wino4Geom::UINSTR % 4 == 0, "36 U pieces of 1 KB per stage, 4 waves");
+constexpr int W4_TILE_OUT = 16;                      // 4 x 4 outputs per lane, tile and channel group: one 16-byte access each
+// vector-memory operations of an epilogue, all issued BEHIND the next tile's first staging: 2 channel groups x 16 stores,
+// + 2 x 16 residual loads with a residual.  A tile's first stage waits until at most W4_TAIL_WAIT operations are
+// outstanding: its staging has landed, the newest stores may still fly.
+constexpr int W4_TAIL_WAIT = 2 * W4_TILE_OUT;
+#define W4_STR2(x) #x
+#define W4_STR(x) W4_STR2(x)
+#define W4_U_PIECES_LIT 9
+#define W4_TAIL_WAIT_LIT 32
+static_assert(W4_U_PIECES == W4_U_PIECES_LIT && W4_TAIL_WAIT == W4_TAIL_WAIT_LIT, "the literals of the s_waitcnt strings");
 
-// pieces of a stage per wave: PIN of the wave's patch (13 row-shaped / 18 tile-linear units) + its 9 of the 36 U pieces
+// pieces of a stage per wave: PIN of the wave's patch (13 row-shaped / 18 tile-linear units) + its W4_U_PIECES of the 36 U pieces
 template <int PIN>
 struct Wino4Lanes {       // per-lane patch offsets (+ class bits, wino4_patch_lanes), one per patch piece
   int a[PIN];
@@ -262,7 +277,7 @@ template <int PIN>
 __device__ __forceinline__ void wino4_piece_asm_n(const int piece, const Wino4Stage& st, const Wino4Dma& d,
                                                   const int (&plm)[PIN], int lane16) {
   switch (piece) {
-#define W4_CASE(I) case I: if constexpr (I < PIN + 9) wino4_piece_asm<I, PIN>(st, d, plm, lane16); break;
+#define W4_CASE(I) case I: if constexpr (I < PIN + W4_U_PIECES) wino4_piece_asm<I, PIN>(st, d, plm, lane16); break;
     W4_CASE(0) W4_CASE(1) W4_CASE(2) W4_CASE(3) W4_CASE(4) W4_CASE(5) W4_CASE(6) W4_CASE(7) W4_CASE(8) W4_CASE(9)
     W4_CASE(10) W4_CASE(11) W4_CASE(12) W4_CASE(13) W4_CASE(14) W4_CASE(15) W4_CASE(16) W4_CASE(17) W4_CASE(18)
     W4_CASE(19) W4_CASE(20) W4_CASE(21) W4_CASE(22) W4_CASE(23) W4_CASE(24) W4_CASE(25) W4_CASE(26)
@@ -273,7 +288,7 @@ __device__ __forceinline__ void wino4_piece_asm_n(const int piece, const Wino4St
 template <int PIN>
 __device__ __forceinline__ void wino4_issue_all(const Wino4Stage& st, const Wino4Lanes<PIN>& pl, int lane, int slw) {
 #pragma unroll
-  for (int i = 0; i < PIN + 9; ++i) wino4_piece<PIN>(i, st, pl, lane, slw);
+  for (int i = 0; i < PIN + W4_U_PIECES; ++i) wino4_piece<PIN>(i, st, pl, lane, slw);   // patch first, then U
 }
 
 // ---- tile-linear units (emb_winograd4_geom.h): what a lane needs of its unit
@@ -338,7 +353,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
   constexpr bool RUN = MODE == 2;    // ... whose patch keeps the row-shaped layout, run by run
   using G = std::conditional_t<MODE == 0, Wino4Geom, std::conditional_t<MODE == 1, Wino4LinGeom, Wino4RunGeom>>;
   constexpr int PIN = G::PINSTR;
-  constexpr int W4_PIECES = PIN + 9;
+  constexpr int W4_PIECES = PIN + W4_U_PIECES;
+  static_assert(W4_PIECES <= 27, "wino4_piece_asm_n spells out 27 cases");
+  // (the epilogue below issues W4_TILE_OUT stores per channel group, and as many residual loads with a residual)
+  static_assert(2 * W4_TILE_OUT * (HAS_R ? 2 : 1) >= W4_TAIL_WAIT, "a tile's first-stage wait counts epilogue operations");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int t = lane & 15, g = lane >> 4;
@@ -435,10 +453,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         // operations complete in order: vmcnt(32) = "the staging has landed" without waiting for the acknowledgement of
         // the stores (~2 k cycles per tile).  (The next group's claim -- an atomic of thread 0 -- is issued in FRONT of
         // the epilogue for that reason.)  The first tile of a workgroup has nothing but its staging in flight.
-        if (PA_W4_STORES_IN_FLIGHT && !first_tile) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        if (PA_W4_STORES_IN_FLIGHT && !first_tile) asm volatile("s_waitcnt vmcnt(" W4_STR(W4_TAIL_WAIT_LIT) ")" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(" W4_STR(W4_U_PIECES_LIT) ")" ::: "memory");   // (the U pieces are the NEWEST of the stage)
       }
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this stage's images have landed (issued a stage ago)

@@ -541,6 +541,22 @@ int pa_lstm_rec_h(const float* xproj, const float* whh_packed, float* out, int n
              64 * pa::LSTMG_MAXU, ndir);
   const int hstride = ((H + 63) / 64) * 64 + 4;
   const size_t lds = sizeof(float) * pa::LSTMG_MT * 2 * 16 * hstride;
+  // 66.5 KB at H = 256, 132 KB at H = 512: above the 64 KB a launch gets without asking, and above what a part with
+  // less LDS than gfx950's 160 KB has at all -- ask for it, and refuse with a message instead of a failed launch
+  {
+    int dev = 0, limit = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&limit, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    PA_REQUIRE(limit <= 0 || lds <= (size_t)limit,
+               "pa_lstm_rec_h: hidden size %d needs %zu bytes of LDS per workgroup, this device offers %d", H, lds, limit);
+    static size_t granted = 0;
+    if (lds > granted) {
+      PA_REQUIRE(hipFuncSetAttribute((const void*)pa::k_lstm_rec_gen, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds) == hipSuccess,
+                 "pa_lstm_rec_h: cannot reserve %zu bytes of dynamic LDS for hidden size %d", lds, H);
+      granted = lds;
+    }
+  }
   pa::ProfScope prof("k_lstm_rec_gen", stream, 2.0 * ntiles * 16 * ndir * T * H * 4.0 * H,
                      4.0 * ntiles * 16 * ndir * T * (4.0 * H + H));
   hipLaunchKernelGGL(pa::k_lstm_rec_gen, dim3(pa::cdiv(ntiles, pa::LSTMG_MT), ndir), dim3(256), lds,

@@ -10,6 +10,8 @@ State-dict layout accepted (core/model.py:244-262):
 """
 from __future__ import annotations
 
+import functools
+import hashlib
 import math
 import os
 from typing import Optional
@@ -565,6 +567,11 @@ def _fold_bn(sd: dict, prefix: str, eps: float = 1e-5):
     return scale, shift
 
 
+#: Winograd guard measurements of this process, by (digest of the ResNet weights, F(4x4) layers, fbank centring): see
+#: `EmbeddingPack._guard_winograd`
+_GUARD_MEASUREMENTS: dict = {}
+
+
 class EmbeddingPack:
     """Device-resident, kernel-ready WeSpeaker ResNet weights + the `pa_emb_weights` struct.
     State-dict layout: resnet.conv1/bn1, resnet.layer{1..4}.{i}.{conv1,bn1,conv2,bn2,shortcut.0,
@@ -583,6 +590,12 @@ class EmbeddingPack:
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype.is_floating_point}
         self.device = device
         self._keep: list[torch.Tensor] = []
+        digest = hashlib.sha1()
+        for k in sorted(sd):
+            if k.startswith("resnet."):
+                digest.update(k.encode())
+                digest.update(sd[k].contiguous().numpy().tobytes())
+        self._weights_digest = digest.hexdigest()
         w = ffi.EmbWeights()
         w.num_mel, w.num_layers = num_mel, 4
         # 0: global mean subtraction; odd K: running mean of K frames (model.WeSpeakerResNet34.fbank_center_kernel)
@@ -678,6 +691,7 @@ class EmbeddingPack:
     WINOGRAD_GUARD_MARGINS = {"f4": 1.5e-5, "f2": 1.0e-5}
 
     @staticmethod
+    @functools.lru_cache(maxsize=2)
     def calibration_chunks(num_samples: int = 48000) -> torch.Tensor:
         """the guard's fixed input: two seeded, speech-like 3-s chunks (glottal-pulse-like harmonic series at 120 /
         210 Hz under a 4-Hz syllable envelope + noise floor), (2, num_samples) float32 at 16 kHz, RMS ~ 0.1"""
@@ -708,8 +722,35 @@ class EmbeddingPack:
         lib = ffi.load()
         w = self.struct
         log = logging.getLogger("pyannote_audio_amd")
-        m4 = float(os.environ.get("PA_WINOGRAD_GUARD_F4", self.WINOGRAD_GUARD_MARGINS["f4"]))
-        m2 = float(os.environ.get("PA_WINOGRAD_GUARD_F2", self.WINOGRAD_GUARD_MARGINS["f2"]))
+        m4 = self._guard_margin("PA_WINOGRAD_GUARD_F4", "f4")
+        m2 = self._guard_margin("PA_WINOGRAD_GUARD_F2", "f2")
+        # the measurement depends on the weights only (the calibration chunks are fixed): a second pack of the same
+        # checkpoint in this process -- another pipeline, another device -- reuses the numbers instead of running the
+        # calibration forward again (three kernels per convolution)
+        key = (self._weights_digest, tuple(sorted(self.winograd4_layers)), int(w.fb_center_kernel))
+        cached = _GUARD_MEASUREMENTS.get(key)
+        if cached is not None:
+            rep = cached
+        else:
+            rep = self._measure_winograd(lib, w)
+            _GUARD_MEASUREMENTS[key] = rep
+        self._apply_guard(rep, m4, m2, log)
+
+    @classmethod
+    def _guard_margin(cls, env: str, which: str) -> float:
+        raw = os.environ.get(env)
+        if raw is None:
+            return cls.WINOGRAD_GUARD_MARGINS[which]
+        try:
+            value = float(raw)
+        except ValueError:
+            raise ValueError(f"{env}={raw!r}: the guard margin must be a number") from None
+        if not (value > 0.0 and math.isfinite(value)):
+            raise ValueError(f"{env}={raw!r}: the guard margin must be positive and finite "
+                             "(PA_WINOGRAD_GUARD=0 switches the guard off)")
+        return value
+
+    def _measure_winograd(self, lib, w):
         with torch.cuda.device(self.device):
             wav = self.calibration_chunks().to(self.device)
             B, N = wav.shape
@@ -719,7 +760,10 @@ class EmbeddingPack:
             ffi.check(lib.pa_emb_calibrate_winograd(w, ffi.ptr(wav.view(-1)), B * N, N, B, N, ffi.ptr(report),
                                                     ffi.ptr(emb), ffi.ptr(ws), ws.numel(), ffi.stream()),
                       "pa_emb_calibrate_winograd")
-            rep = report.cpu().view(-1, 2, 4).numpy()
+            return report.cpu().view(-1, 2, 4).numpy()
+
+    def _apply_guard(self, rep, m4: float, m2: float, log):
+        w = self.struct
         blk = 0
         for l in range(4):
             for i in range(self.num_blocks[l]):
