@@ -165,9 +165,6 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 #ifndef PA_W4_STAMP
 #define PA_W4_STAMP 0
 #endif
-#ifndef PA_W4_ASM_DMA   // staging pieces inside the MFMA run as inline assembly with scalar-only set-up
-#define PA_W4_ASM_DMA 1
-#endif
 #ifndef PA_W4_DEFER_STORES   // stores of channel group 0 issued from inside the column arithmetic of group 1:
 #define PA_W4_DEFER_STORES 1 // 0 = never, 1 = instantiation without residual only, 2 = both (spills: slower)
 #endif
@@ -186,9 +183,6 @@ __device__ __forceinline__ Wino4Stage wino4_stage(const Wino4Ctx& c, const float
 #endif
 #ifndef PA_W4_LATE_BARRIER   // the stage barrier behind most of the input transform (0: in front of it, as in round 4)
 #define PA_W4_LATE_BARRIER 1
-#endif
-#ifndef W4_ROWS_PER_REGION   // rows of the transform's second pass between two scheduling barriers (1, 2, 3 or 6)
-#define W4_ROWS_PER_REGION 1
 #endif
 #if PA_W4_STAMP
 // development instrumentation (never in the product build): s_memtime at the phases of the first 64 stages of
@@ -470,11 +464,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // own: its DMA has landed with the wait above); the LDS wait in front of them covers the mailbox store
       f32x2 x_first[6];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !defined(PA_W4_NOPATCHREAD) && !defined(PA_W4_NOTRANSFORM)
 #pragma unroll
       for (int i = 0; i < 6; ++i)
         x_first[i] = w4_lds_read64(my_patch + pbase0 + W4_PATCH_K(i, 0));
-#endif
       unsigned char* umine = ubufs + buf * G::USLAB_BYTES;
       unsigned char* uother = ubufs + (buf ^ 1) * G::USLAB_BYTES;
       // what the MFMA run below stages: the next stage of this unit, or the first stage of the next group's unit
@@ -517,14 +509,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // ---- input transform V = B^T d B of this lane's tile and channel pair, in registers
       f32x2 v[6][6];
       f32x2 uf_first[2][2];   // (U fragments of the first point pair, read inside the transform)
-#ifdef PA_W4_NOTRANSFORM   // development A/B (timing only): no reads, no arithmetic
-      if constexpr (LATE) stage_barrier();
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) v[i][j] = f32x2{(float)lane, (float)(i + j)};
-      if (false)
-#endif
       {
         const unsigned char* pb0 = my_patch + pbase0;
         const unsigned char* pb1 = my_patch + pbase1;
@@ -533,17 +517,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         // scheduler issues all 36 reads first and the 72 extra registers spill).  (Two columns between the barriers
         // were measured SLOWER: 2 745 instead of 1 700 cycles for setup + transform.)
         f32x2 x[2][6];
-#ifdef PA_W4_NOPATCHREAD   // development A/B (timing only): the arithmetic on register values, no LDS reads
-#define W4_RD(i, j) f32x2{(float)(lane + (i)), (float)(s + (j))}
-#else
 #define W4_RD(i, j) w4_lds_read64(((j) >> 2 ? pb1 : pb0) + W4_PATCH_K(i, j))
-#endif
 #pragma unroll
-#ifdef PA_W4_NOPATCHREAD
-        for (int i = 0; i < 6; ++i) x[0][i] = W4_RD(i, 0);
-#else
         for (int i = 0; i < 6; ++i) x[0][i] = x_first[i];
-#endif
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           if (j + 1 < 6) {
@@ -558,8 +534,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 0; i < 6; i += W4_ROWS_PER_REGION) {   // rows: v[i][.] = B^T tt[i][.]
-          if (i + W4_ROWS_PER_REGION >= 6) {
+        for (int i = 0; i < 6; ++i) {   // rows: v[i][.] = B^T tt[i][.] (one row between two scheduling barriers)
+          if (i == 5) {
             if constexpr (LATE) {
               stage_barrier();
               __builtin_amdgcn_sched_barrier(0);
@@ -572,8 +548,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
               for (int cg = 0; cg < 2; ++cg) uf_first[e][cg] = w4_lds_read64(umine + ubase + wino4_u_k(e, cg));
             __builtin_amdgcn_sched_barrier(0);
           }
-#pragma unroll
-          for (int r = 0; r < W4_ROWS_PER_REGION; ++r) wino4_bt(tt[i + r], v[i + r], kc);
+          wino4_bt(tt[i], v[i], kc);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -585,7 +560,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
       // its producer); U fragments of the next pair are read while this pair's MFMAs issue.  The MFMAs are inline
       // assembly because the accumulators must be PINNED: 32 points in the 256 AccVGPRs, 4 in architectural
       // registers (left to the register allocator, 288 accumulators + the transform spill ~200 registers).
-#if PA_W4_ASM_DMA
       int plm[PIN];
       if constexpr (LIN) {
 #pragma unroll
@@ -595,7 +569,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         for (int i = 0; i < PIN; ++i) plm[i] = pl.a[i] & nst.keep;
       }
       const Wino4Dma dma{w4_lds_addr(my_patch), w4_lds_addr(uother) + 1024u * slw, nst.usoff + 1024 * slw};
-#endif
       auto mfma_run = [&](auto first_stage) {
         constexpr bool FIRST = decltype(first_stage)::value;
         const unsigned char* ub = umine + ubase;
@@ -604,11 +577,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int cg = 0; cg < 2; ++cg) {
-#if defined(PA_W4_NOTRANSFORM)
-            uf[0][e][cg] = w4_lds_read64(ub + wino4_u_k(e, cg));
-#else
             uf[0][e][cg] = uf_first[e][cg];
-#endif
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -631,7 +600,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
               else W4_MFMA_V(accv[xi >= W4_AGPR_POINTS ? xi - W4_AGPR_POINTS : 0][cg], a, b);
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifndef PA_W4_NOUREAD   // (development A/B: the same fragments for every point -> what the U reads cost)
             if ((m == 0 || m == 2) && xp + 2 < 36) {      // U fragments of the next pair, one point per slot
               const int en = m >> 1;
 #pragma unroll
@@ -639,25 +607,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(
                 uf[par ^ 1][en][c2] = w4_lds_read64(ub + wino4_u_k(xp + 2 + en, c2));
               __builtin_amdgcn_sched_barrier(0);
             }
-#else
-            if (xp == 0 && m == 0) {
-#pragma unroll
-              for (int en = 0; en < 2; ++en)
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) uf[1][en][c2] = uf[0][en][c2];
-            }
-#endif
-#ifndef PA_W4_NODMA   // (development A/B, timing only: no staging from inside the run)
             if ((m == 4 || m == 6) && stage_next) {       // wave-uniform; pieces xp, xp + 1 of the next stage
               const int piece = xp + ((m - 4) >> 1);
-#if PA_W4_ASM_DMA
               if (piece < W4_PIECES) wino4_piece_asm_n<PIN>(piece, nst, dma, plm, lane16);
-#else
-              if (piece < W4_PIECES) wino4_piece<PIN>(piece, nst, pl, lane, slw);
-#endif
               __builtin_amdgcn_sched_barrier(0);
             }
-#endif
           }
         }
       };
