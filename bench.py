@@ -190,8 +190,9 @@ def load_traffic(kernel: str, config: str = "pipeline"):
     STATIC one and says which file / commit it comes from.  A stage configuration (`--config seg5s|emb3s`) launches
     the kernels on other shapes than the pipeline does: it only ever reads a capture of ITS OWN command
     (profiles/r5_traffic_<config>.json, tools/capture_config_traffic.sh) -- or reports null."""
-    names = ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r3a_traffic.json", "r2_traffic.json",
-             "r1_traffic.json") if config == "pipeline" else (f"r5_traffic_{config}.json",)
+    names = ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r3a_traffic.json",
+             "r2_traffic.json", "r1_traffic.json") if config == "pipeline" else \
+        (f"r6_traffic_{config}.json", f"r5_traffic_{config}.json")
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fp:

@@ -144,6 +144,66 @@ def pipelined_owned(items: Iterable[Any], front: Callable[[Any, Callable[[], Non
         tails.shutdown(wait=clean, cancel_futures=not clean)
 
 
+def run_ahead(make_iter: Callable[[], Iterator[Any]], depth: int = 1, context: Callable[[], Any] = None) -> Iterator[Any]:
+    """`make_iter()` iterated in a PRODUCER thread, up to `depth` finished results ahead of the consumer: what the
+    consumer does with result i (the reference's benchmark loop serialises it and writes its RTTM,
+    src/pyannote/audio/__main__.py:700-720) no longer suspends the generator that would be starting the front end of
+    item i + 2 -- the GPU keeps working while the host writes.  Results in order; an exception of the producer is raised
+    by the consumer at the position where it happened; a consumer that stops early (break / close / exception) stops
+    the producer at its next result and closes the inner iterator there, in the producer's thread.  `context()`: a
+    context manager entered in the producer thread (the CUDA device of the pipeline: it is a per-thread setting)."""
+    import contextlib
+    import queue
+    results: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+    stop = threading.Event()
+
+    def offer(entry) -> bool:
+        while not stop.is_set():
+            try:
+                results.put(entry, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def produce():
+        it = None
+        try:
+            with (context() if context is not None else contextlib.nullcontext()):
+                it = make_iter()
+                for value in it:
+                    if not offer(("value", value)):
+                        break
+        except BaseException as exc:      # handed to the consumer, raised there
+            offer(("error", exc))
+        finally:
+            try:
+                if it is not None and hasattr(it, "close"):
+                    it.close()
+            finally:
+                offer(("done", None))
+
+    worker = threading.Thread(target=produce, name="pa-run-ahead", daemon=True)
+    worker.start()
+    try:
+        while True:
+            kind, payload = results.get()
+            if kind == "value":
+                yield payload
+            elif kind == "error":
+                raise payload
+            else:
+                return
+    finally:
+        stop.set()
+        while worker.is_alive():          # unblock a producer waiting for room, then let it close the inner iterator
+            try:
+                results.get_nowait()
+            except queue.Empty:
+                pass
+            worker.join(timeout=0.05)
+
+
 class ReadAhead:
     """`load(items[i + 1])` runs in ONE worker thread while the caller works on item i: `take(i)` hands out
     `load(items[i])` (started by `take(i - 1)`, or now) and starts the next one.  At most one result is held ahead of

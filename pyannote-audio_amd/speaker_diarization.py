@@ -41,7 +41,7 @@ from .diarization import optimal_mapping, set_num_speakers, to_annotation
 from .inference import Inference
 from .model import Model
 from .pipeline import ParamDict, Pipeline, Uniform
-from .pipelining import ReadAhead, pipelined, pipelined_owned
+from .pipelining import ReadAhead, pipelined, pipelined_owned, run_ahead
 from .speaker_verification import PipelineModel, PretrainedSpeakerEmbedding, get_model
 
 
@@ -520,10 +520,21 @@ class SpeakerDiarization(Pipeline):
             line["tail_done"] = time.perf_counter() - t_batch
             return out
 
-        try:
-            items = [(i, f, b) for i, (f, b) in enumerate(zip(files, all_bounds))]
+        items = [(i, f, b) for i, (f, b) in enumerate(zip(files, all_bounds))]
+
+        def stream():
             for (_, file, _), out in pipelined(items, front_of, tail_of, self.TAIL_GATE_TIMEOUT):
                 yield file, out
+
+        try:
+            if hook is None and len(items) > 2 and os.environ.get("PA_BATCH_RUN_AHEAD", "1") != "0":
+                # The caller's loop body (the reference's benchmark: serialize() + write_rttm per file) runs while this
+                # generator is suspended -- and the suspended generator is what would start the front end of the file
+                # after next.  One result ahead, produced in its own thread, keeps the GPU busy meanwhile.  (Not with a
+                # hook: hooks are the caller's code and expect the caller's thread.)
+                yield from run_ahead(stream, depth=1, context=lambda: torch.cuda.device(device))
+            else:
+                yield from stream()
         finally:
             ahead.close()
 

@@ -44,6 +44,25 @@ def test_apply_batch_equals_sequential(pipeline_dir, gpu_device):
         assert np.array_equal(out.speaker_embeddings, ref.speaker_embeddings)
     with pytest.raises(ValueError, match="distinct URIs"):
         pipeline([files[0], dict(files[1], uri=files[0]["uri"])])
+    # without a hook the results are produced one ahead of the consumer in a worker thread (pipelining.run_ahead); a
+    # hook is the caller's code and keeps running in the caller's thread, and the results are the same either way
+    import threading
+    seen = set()
+
+    def hook(step, artefact, file=None, total=None, completed=None):
+        seen.add(threading.current_thread().name)
+
+    hooked = list(pipeline(files, hook=hook))
+    assert seen == {threading.current_thread().name}
+    for (f, out), ref in zip(hooked, want):
+        assert _turns(out.speaker_diarization) == _turns(ref.speaker_diarization), f["uri"]
+    # a consumer that stops after the first result leaves nothing behind that the next call trips over
+    it = iter(pipeline(files))
+    first = next(it)
+    it.close()
+    assert _turns(first[1].speaker_diarization) == _turns(want[0].speaker_diarization)
+    again = list(pipeline(files))
+    assert _turns(again[-1][1].speaker_diarization) == _turns(want[-1].speaker_diarization)
 
 
 def test_files_on_disk_equal_resident_waveforms(pipeline_dir, gpu_device, tmp_path):

@@ -309,3 +309,83 @@ def test_read_ahead_loads_one_item_ahead_in_order_and_raises_at_the_right_take()
     again = ReadAhead(["x", "y"], load)
     assert again.take(1) == "Y" and again.take(0) == "X"
     again.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# run_ahead: the producer of results keeps going while the consumer works on the previous one
+# ---------------------------------------------------------------------------------------------------------------
+def test_run_ahead_keeps_order_and_overlaps_the_consumer():
+    import threading
+    from pyannote_audio_amd.pipelining import run_ahead
+    made_in = []
+
+    def make():
+        for i in range(6):
+            time.sleep(0.05)                      # "front end + tail of file i"
+            made_in.append(threading.current_thread().name)
+            yield i
+
+    t0 = time.perf_counter()
+    got = []
+    for v in run_ahead(make, depth=1):
+        time.sleep(0.05)                          # "serialize + write_rttm"
+        got.append(v)
+    dt = time.perf_counter() - t0
+    assert got == list(range(6))
+    assert set(made_in) == {"pa-run-ahead"}       # produced in the worker thread
+    assert dt < 0.50, dt                          # 6 x (0.05 + 0.05) = 0.6 s in turns; ~0.35 s overlapped
+    assert list(run_ahead(lambda: iter(()))) == []
+
+
+def test_run_ahead_raises_at_the_right_position_and_stops_when_abandoned():
+    import threading
+    from pyannote_audio_amd.pipelining import run_ahead
+    closed = threading.Event()
+    produced = []
+
+    def make():
+        try:
+            for i in range(100):
+                if i == 3:
+                    raise ValueError("file 3 is broken")
+                produced.append(i)
+                yield i
+        finally:
+            closed.set()
+
+    got = []
+    with pytest.raises(ValueError, match="file 3 is broken"):
+        for v in run_ahead(make):
+            got.append(v)
+    assert got == [0, 1, 2] and closed.wait(2.0)
+
+    closed.clear()
+    produced.clear()
+
+    def endless():
+        try:
+            i = 0
+            while True:
+                produced.append(i)
+                yield i
+                i += 1
+        finally:
+            closed.set()
+
+    it = run_ahead(endless, depth=2)
+    assert next(it) == 0 and next(it) == 1
+    it.close()                                    # the consumer walks away
+    assert closed.wait(2.0)                       # ... the inner iterator was closed, in the producer's thread
+    assert len(produced) <= 6                     # and it was never more than depth + 1 results ahead
+    # the context manager is entered in the producer thread
+    where = []
+
+    class Ctx:
+        def __enter__(self):
+            where.append(threading.current_thread().name)
+
+        def __exit__(self, *a):
+            where.append("exit")
+
+    assert list(run_ahead(lambda: iter([1, 2]), context=Ctx)) == [1, 2]
+    assert where == ["pa-run-ahead", "exit"]
