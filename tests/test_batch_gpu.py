@@ -44,8 +44,9 @@ def test_apply_batch_equals_sequential(pipeline_dir, gpu_device):
         assert np.array_equal(out.speaker_embeddings, ref.speaker_embeddings)
     with pytest.raises(ValueError, match="distinct URIs"):
         pipeline([files[0], dict(files[1], uri=files[0]["uri"])])
-    # without a hook the results are produced one ahead of the consumer in a worker thread (pipelining.run_ahead); a
-    # hook is the caller's code and keeps running in the caller's thread, and the results are the same either way
+    # without a hook the results are produced one ahead of the consumer in a worker thread (pipelining.run_ahead); with
+    # a hook -- the caller's code, called from the main thread (front end) and from the tail thread (back end) as
+    # before -- they are not, and the results are the same either way
     import threading
     seen = set()
 
@@ -53,7 +54,7 @@ def test_apply_batch_equals_sequential(pipeline_dir, gpu_device):
         seen.add(threading.current_thread().name)
 
     hooked = list(pipeline(files, hook=hook))
-    assert seen == {threading.current_thread().name}
+    assert threading.current_thread().name in seen and "pa-run-ahead" not in seen
     for (f, out), ref in zip(hooked, want):
         assert _turns(out.speaker_diarization) == _turns(ref.speaker_diarization), f["uri"]
     # a consumer that stops after the first result leaves nothing behind that the next call trips over
