@@ -181,3 +181,38 @@ def test_fuzz_embedding_lengths_and_masks(gpu_device):
         out = eng.forward(x.to(gpu_device), masks.to(gpu_device))
         torch.cuda.synchronize()
         assert north_star_ratio(f"fuzz_emb_N{N}", out, ref) <= 1.0, N
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_count_and_reconstruct(gpu_device, seed):
+    """speaker_count / reconstruct / to_diarization on random chunk grids (1 .. 80 chunks of 1 .. 700 frames, 1 .. 5 local
+    speakers, steps from a tenth of a chunk to a whole chunk, up to 8 clusters, unassigned speakers): bit-exact
+    against the oracle's restatement of the reference's loops"""
+    import numpy as np
+    from oracle import pipeline as op
+    from pyannote_audio_amd import frames as fo
+    from pyannote_audio_amd.core import SlidingWindow
+    rng = np.random.default_rng(seed)
+    for _ in range(10):
+        C, F, S = int(rng.integers(1, 81)), int(rng.integers(1, 701)), int(rng.integers(1, 6))
+        frame_step = 0.016875
+        dur = F * frame_step + 0.045          # a chunk of F frames
+        step = float(rng.choice([0.1, 0.25, 0.5, 0.73, 1.0])) * dur
+        seg = (rng.uniform(size=(C, F, S)) < rng.uniform(0.05, 0.9)).astype(np.float32)
+        seg[rng.uniform(size=C) < 0.15] = 0.0                      # silent chunks
+        chunks_o, frames_o = op.SW(0.0, dur, step), op.SW(0.0, 0.0619375, frame_step)
+        chunks = SlidingWindow(start=0.0, duration=dur, step=step)
+        frames = SlidingWindow(start=0.0, duration=0.0619375, step=frame_step)
+        dev = fo.as_device_segmentation(seg, gpu_device)
+        want_count, _ = op.speaker_count(seg, chunks_o, frames_o)
+        got_count = fo.speaker_count(dev, chunks, frames)
+        case = (C, F, S, round(step / dur, 2))
+        assert got_count.data.shape == want_count.shape and np.array_equal(got_count.data, want_count), case
+        K = int(rng.integers(1, 9))
+        hard = rng.integers(0, K, size=(C, S))
+        hard[rng.uniform(size=(C, S)) < 0.25] = -2
+        hard[0, 0] = K - 1
+        count = np.minimum(want_count, int(rng.integers(1, 4))).astype(np.int8)
+        want = op.reconstruct(seg, chunks_o, hard, count, frames_o)
+        got = fo.Reconstructor(dev, chunks, frames, hard, count).discretize().data
+        assert got.shape == want.shape and np.array_equal(got, want), case
