@@ -396,8 +396,11 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
             segmentation_batch_size: int = 32, embedding_batch_size: int = 32,
             num_speakers=None, min_speakers=None, max_speakers=None,
             method="centroid", threshold=0.7045654963945799, min_cluster_size=12,
-            segmentation_threshold: float = 0.5, min_num_samples: int = 400) -> OracleOutput:
-    """SpeakerDiarization.apply (speaker_diarization.py:530-784) for the 3.1 configuration."""
+            segmentation_threshold: float = 0.5, min_num_samples: int = 400, cluster=None) -> OracleOutput:
+    """SpeakerDiarization.apply (speaker_diarization.py:530-784) for the 3.1 configuration.  `cluster`: another
+    clustering step with the call contract of `self.clustering(...)` there (:660-668) -- cluster(embeddings,
+    segmentations, num_clusters=, min_clusters=, max_clusters=) -> (hard, soft, centroids) -- e.g. oracle.vbx.vbx_clustering
+    bound to a PLDA for the 4.x / community-1 configuration; default: agglomerative clustering with the arguments above."""
     import time
     timings = {}
     min_speakers_ = num_speakers or min_speakers or 1
@@ -424,10 +427,14 @@ def diarize(seg_model, emb_model, waveform: torch.Tensor, sample_rate: int = 160
                                 min_num_samples=min_num_samples)
     timings["embeddings"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    hard_clusters, _, centroids = clustering(
-        np.array(embeddings), segmentations, num_clusters=num_speakers, min_clusters=min_speakers_,
-        max_clusters=max_speakers_, method=method, threshold=threshold,
-        min_cluster_size=min_cluster_size)
+    if cluster is not None:
+        hard_clusters, _, centroids = cluster(np.array(embeddings), segmentations, num_clusters=num_speakers,
+                                              min_clusters=min_speakers_, max_clusters=max_speakers_)
+    else:
+        hard_clusters, _, centroids = clustering(
+            np.array(embeddings), segmentations, num_clusters=num_speakers, min_clusters=min_speakers_,
+            max_clusters=max_speakers_, method=method, threshold=threshold,
+            min_cluster_size=min_cluster_size)
     timings["clustering"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     count = np.minimum(count, max_speakers_).astype(np.int8)

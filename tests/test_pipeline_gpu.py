@@ -91,12 +91,27 @@ def test_full_pipeline_matches_oracle(pipeline_dir, synthetic_models, gpu_device
     assert "SPEAKER synth 1" in ann.to_rttm()
 
 
-def test_verify_checkpoint_tool(pipeline_dir, gpu_device, tmp_path):
+@pytest.mark.parametrize("clustering", ["AgglomerativeClustering", "VBxClustering"])
+def test_verify_checkpoint_tool(pipeline_dir, synthetic_models, gpu_device, tmp_path, clustering):
     """tools/verify_checkpoint.py end to end on the seeded checkpoints and the reference's 30-s fixture: every row of
-    its table passes (what the owner of real weights runs on theirs)"""
+    its table passes (what the owner of real weights runs on theirs) -- the 3.1 configuration and the community-1 one
+    (VBx + PLDA)"""
     import importlib.util
     import json
     import os
+    if clustering == "VBxClustering":
+        from conftest import write_pipeline_dir
+        from oracle.vbx import synth_plda
+        pipeline_dir = str(tmp_path / "community")
+        write_pipeline_dir(pipeline_dir, *synthetic_models, config_extra={
+            "pipeline": {"name": "pyannote.audio.pipelines.SpeakerDiarization",
+                         "params": {"clustering": "VBxClustering", "embedding": "$model/embedding",
+                                    "embedding_batch_size": 32, "embedding_exclude_overlap": True,
+                                    "plda": "$model/plda", "segmentation": "$model/segmentation",
+                                    "segmentation_batch_size": 32}},
+            "params": {"clustering": {"threshold": 0.6, "Fa": 0.07, "Fb": 0.8},
+                       "segmentation": {"min_duration_off": 0.0}}})
+        synth_plda(os.path.join(pipeline_dir, "plda"))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("verify_checkpoint", os.path.join(root, "tools", "verify_checkpoint.py"))
     tool = importlib.util.module_from_spec(spec)

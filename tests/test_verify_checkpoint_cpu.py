@@ -49,3 +49,27 @@ def test_a_checkpoint_that_does_not_fit_the_class_is_reported(tmp_path):
                        pm.WeSpeakerResNet34.ARCHITECTURE, pm.embedding_specifications())
     with pytest.raises(RuntimeError, match="resnet.layer3.2.conv1.weight"):
         load_tool().main([str(tmp_path), os.path.join(ROOT, "tests", "golden", "sample.wav"), "--oracle-only"])
+
+
+def test_oracle_half_with_the_vbx_configuration(tmp_path, capsys):
+    """the 4.x / community-1 layout: `clustering: VBxClustering` + `plda: $model/plda` -- the tool binds the oracle's VBx
+    step (pinned to the reference's VBxClustering by tests/test_reference_pipeline.py) to the directory's PLDA"""
+    from conftest import write_pipeline_dir
+    from oracle.models import seeded_pyannet, seeded_wespeaker
+    from oracle.vbx import synth_plda
+    write_pipeline_dir(tmp_path, seeded_pyannet(), seeded_wespeaker(), config_extra={
+        "pipeline": {"name": "pyannote.audio.pipelines.SpeakerDiarization",
+                     "params": {"clustering": "VBxClustering", "embedding": "$model/embedding",
+                                "embedding_batch_size": 32, "embedding_exclude_overlap": True,
+                                "plda": "$model/plda", "segmentation": "$model/segmentation",
+                                "segmentation_batch_size": 32}},
+        "params": {"clustering": {"threshold": 0.6, "Fa": 0.07, "Fb": 0.8},
+                   "segmentation": {"min_duration_off": 0.0}}})
+    synth_plda(str(tmp_path / "plda"))
+    out_json = str(tmp_path / "report.json")
+    rc = load_tool().main([str(tmp_path), os.path.join(ROOT, "tests", "golden", "sample.wav"), "--max-seconds", "11",
+                           "--chunks", "1", "--oracle-only", "--json", out_json])
+    text = capsys.readouterr().out
+    rep = json.load(open(out_json))
+    assert rc == 0 and rep["clustering"] == "VBxClustering" and "PLDA <-" in text
+    assert any(r["stage"] == "pipeline" for r in rep["rows"])

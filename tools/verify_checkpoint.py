@@ -107,9 +107,11 @@ def main(argv=None) -> int:
     root, config, seg_path, emb_path = resolve(args.pipeline)
     name = config["pipeline"]["name"].rsplit(".", 1)[-1]
     pparams = config["pipeline"]["params"]
-    if name != "SpeakerDiarization" or pparams.get("clustering", "VBxClustering") != "AgglomerativeClustering":
+    clustering_name = pparams.get("clustering", "VBxClustering")
+    if name != "SpeakerDiarization" or clustering_name not in ("AgglomerativeClustering", "VBxClustering"):
         raise SystemExit("verify_checkpoint: the end-to-end leg restates SpeakerDiarization with AgglomerativeClustering "
-                         f"(speaker-diarization-3.1); this config is {name} / {pparams.get('clustering')}")
+                         "(speaker-diarization-3.1) or VBxClustering + PLDA (community-1); this config is "
+                         f"{name} / {clustering_name}")
     seg_o, seg_arch, seg_spec = oracle_from_checkpoint(seg_path)
     emb_o, emb_arch, _ = oracle_from_checkpoint(emb_path)
     print(f"segmentation: {seg_arch} <- {seg_path}\nembedding:    {emb_arch} <- {emb_path}   (strict state-dict match: ok)")
@@ -127,7 +129,17 @@ def main(argv=None) -> int:
               method=cl.get("method", "centroid"), threshold=cl.get("threshold", 0.7045654963945799),
               min_cluster_size=cl.get("min_cluster_size", 12),
               segmentation_threshold=inst.get("segmentation", {}).get("threshold", 0.5))
-    report = {"audio_seconds": seconds, "segmentation": seg_arch, "embedding": emb_arch, "tolerance":
+    if clustering_name == "VBxClustering":
+        # the 4.x / community-1 configuration: AHC initialisation + VBx over PLDA features (pipelines/clustering.py:550-669,
+        # utils/vbx.py); the PLDA directory holds xvec_transform.npz + plda.npz (core/plda.py:33-60)
+        import oracle.vbx as ov
+        plda_dir = str(pparams.get("plda", "")).replace("$model", root)
+        plda = ov.PLDA(os.path.join(plda_dir, "xvec_transform.npz"), os.path.join(plda_dir, "plda.npz"))
+        vb = {k: cl[k] for k in ("threshold", "Fa", "Fb") if k in cl}
+        kw["cluster"] = lambda emb, seg, **bounds: ov.vbx_clustering(emb, seg, plda, **vb, **bounds)
+        print(f"clustering:   VBxClustering, PLDA <- {plda_dir}, {vb}")
+    report = {"audio_seconds": seconds, "segmentation": seg_arch, "embedding": emb_arch, "clustering": clustering_name,
+              "tolerance":
               {"rtol": RTOL, "atol": ATOL, "hard_decision_gap": GAP}, "rows": []}
 
     def row(stage, what, value, verdict=None):
