@@ -131,7 +131,8 @@ def test_fuzz_fbank_lengths(gpu_device):
     from pyannote_audio_amd.weights import EmbeddingPack
     lib = ffi.load()
     model = seeded_wespeaker(seed=4321)
-    w = EmbeddingPack(model.state_dict(), gpu_device, guard=False).struct
+    pack = EmbeddingPack(model.state_dict(), gpu_device, guard=False)   # (kept alive: it owns the device tables)
+    w = pack.struct
     rng = torch.Generator().manual_seed(9)
     lengths = [400, 401, 559, 560, 561, 719, 720, 1000, 4799, 4800, 16000, 23456, 48001]
     for N in lengths:
