@@ -52,60 +52,68 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ fb, int 
       if (i < n) xs[(ff + 1) * STEM_LD + tt] = v[k];
     }
   }
-  const int p = tid >> 2, cg = (tid & 3) * 8;
-  float w[9][8], sh[8];
+  // thread = (channel quad q, time steps pl and pl + 32): the 8 lanes of a time step store its 32 channels as ONE full
+  // 128-byte line per instruction (round 6; before: 8 channels of one time step per thread = two 16-byte stores 32 bytes
+  // apart per lane, half-filled sectors: 304 instead of 157 cycles per KB on the CU's store path,
+  // profiles/r6_store_stagger_probe.txt).  Same products in the same order per output: bit-identical results.
+  const int q4 = (tid & 7) * 4, pl = tid >> 3;
+  float w[9][4], sh[4];
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) w[k][c] = w9[k * 32 + cg + c];
+    for (int c = 0; c < 4; ++c) w[k][c] = w9[k * 32 + q4 + c];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) sh[c] = shift[cg + c];
+  for (int c = 0; c < 4; ++c) sh[c] = shift[q4 + c];
   __syncthreads();
-  if (t0 + p >= T) return;
-  // rolling 3 x 3 window: rows f - 1, f, f + 1 (LDS rows f, f + 1, f + 2), columns p .. p + 2
-  float x0[3], x1[3], x2[3];
+  // rolling 3 x 3 windows of the two time steps: rows f - 1, f, f + 1 (LDS rows f, f + 1, f + 2), columns p .. p + 2
+  float x0[2][3], x1[2][3], x2[2][3];
 #pragma unroll
-  for (int dt = 0; dt < 3; ++dt) {
-    x0[dt] = xs[0 * STEM_LD + p + dt];
-    x1[dt] = xs[1 * STEM_LD + p + dt];
-  }
-  float* o = out + ((long)b * F * T + t0 + p) * 32 + cg;
-  for (int f = 0; f < F; ++f) {
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt) x2[dt] = xs[(f + 2) * STEM_LD + p + dt];
-    float acc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-    // (df outer, dt inner: the summation order of the previous kernel, so the results are bit-identical)
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = fmaf(x0[dt], w[dt][c], acc[c]);
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = fmaf(x1[dt], w[3 + dt][c], acc[c]);
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = fmaf(x2[dt], w[6 + dt][c], acc[c]);
-    float4 o0, o1;
-    o0.x = fmaxf(acc[0] + sh[0], 0.f);
-    o0.y = fmaxf(acc[1] + sh[1], 0.f);
-    o0.z = fmaxf(acc[2] + sh[2], 0.f);
-    o0.w = fmaxf(acc[3] + sh[3], 0.f);
-    o1.x = fmaxf(acc[4] + sh[4], 0.f);
-    o1.y = fmaxf(acc[5] + sh[5], 0.f);
-    o1.z = fmaxf(acc[6] + sh[6], 0.f);
-    o1.w = fmaxf(acc[7] + sh[7], 0.f);
-    float* of = o + (long)f * T * 32;
-    reinterpret_cast<float4*>(of)[0] = o0;
-    reinterpret_cast<float4*>(of)[1] = o1;
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt) {
-      x0[dt] = x1[dt];
-      x1[dt] = x2[dt];
+      x0[h][dt] = xs[0 * STEM_LD + pl + 32 * h + dt];
+      x1[h][dt] = xs[1 * STEM_LD + pl + 32 * h + dt];
     }
+  const bool ok0 = t0 + pl < T, ok1 = t0 + pl + 32 < T;
+  float* o = out + ((long)b * F * T + t0 + pl) * 32 + q4;
+  for (int f = 0; f < F; ++f) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) x2[h][dt] = xs[(f + 2) * STEM_LD + pl + 32 * h + dt];
+    float* of = o + (long)f * T * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = 0.f;
+      // (df outer, dt inner: the summation order of the first kernel, so the results stay bit-identical)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(x0[h][dt], w[dt][c], acc[c]);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(x1[h][dt], w[3 + dt][c], acc[c]);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(x2[h][dt], w[6 + dt][c], acc[c]);
+      float4 o4;
+      o4.x = fmaxf(acc[0] + sh[0], 0.f);
+      o4.y = fmaxf(acc[1] + sh[1], 0.f);
+      o4.z = fmaxf(acc[2] + sh[2], 0.f);
+      o4.w = fmaxf(acc[3] + sh[3], 0.f);
+      if (h == 0 ? ok0 : ok1) *reinterpret_cast<float4*>(of + 32 * 32 * h) = o4;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        x0[h][dt] = x1[h][dt];
+        x1[h][dt] = x2[h][dt];
+      }
   }
 }
 

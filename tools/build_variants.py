@@ -22,6 +22,7 @@ VARIANTS = {   # tag -> (source file, extra flags, git revision of the source or
     "w4waitstores": ("emb_winograd4.hip", "-DPA_W4_STORES_IN_FLIGHT=0", None),   # F(4x4): a tile's first stage waits for the previous tile's stores
     "w4earlybar": ("emb_winograd4.hip", "-DPA_W4_LATE_BARRIER=0", None),   # F(4x4): stage barrier in front of the transform (round 4)
     "w4stamp": ("emb_winograd4.hip", "-DPA_W4_STAMP=1", None),                   # F(4x4): phase stamps (tools/wino4_stamps.py)
+    "stem_r5": ("emb_resnet.hip", "", "3a63397"),   # k_stem with 8 channels of one time step per thread (rounds 2-5)
     "stamp": ("emb_winograd.hip", "-DPA_WINO_STAMP=1", None),
     "norefresh": ("emb_winograd.hip", "-DPA_WINO_REFRESH=0", None),   # 128-channel residual kernel without the pinned residual loads
     "nortouch": ("emb_winograd.hip", "-DPA_WINO_RTOUCH=0", None),   # without the residual line touch

@@ -30,10 +30,30 @@ __global__ __launch_bounds__(256, 1) void k_store_stagger(float* buf, long wave_
   const long long t0 = __builtin_readcyclecounter();
   long long t1;
   if ((mask >> w) & 1) {
+    if (pattern == 3) {
+      // k_stem's pair of stores: lane i writes 16 B at 32 i, then the other 16 B of its 32 (two half-filled sectors per
+      // lane and instruction)
+      const int off16 = lane * 32;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off16 + 16 * (i & 1)), "s"(srd),
+                     "s"(__builtin_amdgcn_readfirstlane((i >> 1) * row_stride + zero)) : "memory");
+      }
+    } else if (pattern == 2) {
+      // the direct convolution's epilogue (csrc/emb_resnet.hip): ONE dword per lane, lanes 0-31 = 32 consecutive channels
+      // of a pixel (128 B), lanes 32-63 the pixel four further on
+      const int off4 = (lane & 31) * 4 + (lane >> 5) * 4 * seg_stride;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        asm volatile("buffer_store_dword %0, %1, %2, %3 offen" :: "v"(v[0]), "v"(off4), "s"(srd),
+                     "s"(__builtin_amdgcn_readfirstlane(i * row_stride + zero)) : "memory");
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(v), "v"(off), "s"(srd),
                    "s"(__builtin_amdgcn_readfirstlane(i * row_stride + zero)) : "memory");
+    }
     }
     t1 = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

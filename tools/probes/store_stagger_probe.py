@@ -10,7 +10,7 @@ sink = torch.zeros(1024, device=dev)
 for seg_stride in (1024, 2048, 4096):
     wave_bytes = NS * row_stride + 16 * (seg_stride + 4160) + 4096
     buf = torch.empty(wave_bytes * cus * 4 // 4, dtype=torch.float32, device=dev)
-    for pattern, pname in ((0, "16 x 64 B"), (1, "8 x 128 B")):
+    for pattern, pname in ((0, "16 x 64 B"), (1, "8 x 128 B"), (2, "dword: 2 x 128 B"), (3, "stem: 64 x 16 B @32")):
         for mask, name in ((15, "all four waves store"), (1, "wave 0 stores, 3 waves run MFMAs"), (3, "waves 0-1 store, 2 run MFMAs"),
                            (5, "waves 0 and 2 store, 2 run MFMAs")):
             for rep in range(3):
