@@ -217,3 +217,42 @@ def test_fuzz_count_and_reconstruct(gpu_device, seed):
         want = op.reconstruct(seg, chunks_o, hard, count, frames_o)
         got = fo.Reconstructor(dev, chunks, frames, hard, count).discretize().data
         assert got.shape == want.shape and np.array_equal(got, want), case
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_segmentation_strided(gpu_device, seed):
+    """pa_seg_forward on random chunk grids: 1 .. 40 chunks of 1.2 .. 11 s, hops from 1/16 of a chunk to a whole chunk
+    (chunk starts at any sample: the shared-sinc path needs hops that are multiples of the sinc stride, the per-chunk
+    path takes the rest), the last chunk running past the end of the waveform by a random amount (zero padded, as
+    core/inference.py:270-278 pads an orphan chunk): log-probabilities within the north-star tolerance, hard decisions
+    identical outside the 1e-4 gap"""
+    from oracle import Powerset, seeded_pyannet
+    from pyannote_audio_amd.segmentation import SegmentationEngine
+    from pyannote_audio_amd.weights import SegmentationPack
+    model = seeded_pyannet(seed=1234, num_layers=4)
+    eng = SegmentationEngine(SegmentationPack(model.state_dict(), {"lstm": {"num_layers": 4}}, 7, 3, 2, gpu_device))
+    rng = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))   # noqa: E731
+    for _ in range(6):
+        N = ri(19200, 176000)
+        B = ri(1, 40)
+        stride = max(1, N // ri(1, 16)) if ri(0, 1) else ri(1, N)
+        if ri(0, 1):
+            stride = max(10, stride // 10 * 10)
+        missing = ri(0, N // 2) if B > 1 or ri(0, 1) else 0
+        total = stride * (B - 1) + N - missing
+        wav = (0.1 * torch.randn(total, generator=rng) + 0.03 * torch.sin(torch.arange(total) * 0.013)).clamp(-1, 1)
+        chunks = torch.zeros(B, 1, N)
+        for b in range(B):
+            piece = wav[b * stride: b * stride + N]
+            chunks[b, 0, :piece.numel()] = piece
+        with torch.inference_mode():
+            ref = model(chunks)
+        logp, ml = eng.forward_strided(wav.to(gpu_device), stride, B, N)
+        torch.cuda.synchronize()
+        case = (B, N, stride, missing)
+        assert logp.shape == ref.shape, case
+        assert north_star_ratio(f"fuzz_seg_{case}", logp, ref) <= 1.0, case
+        top2 = ref.topk(2, dim=-1).values
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-4
+        assert torch.equal(ml.cpu()[safe], Powerset(3, 2)(ref).to(torch.uint8)[safe]), case
