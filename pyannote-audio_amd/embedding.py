@@ -25,19 +25,32 @@ class EmbeddingEngine:
         # kernel 0.55 -> 0.62 of peak); groups sized to the 256-MiB Infinity Cache (8 chunks, so that a convolution
         # would read its predecessor's output on-die) are far on the wrong side of that trade.  The chunks of a
         # file are split EVENLY over the groups (3 591 = 2 x 1 796).
-        self.max_chunks = max_chunks or int(os.environ.get("PA_EMB_BATCH", "2048"))
+        # Round 6: the limit is a WORKSPACE SIZE, not a chunk count -- 96 GB, i.e. 3 096 chunks of 10 s (a one-hour file
+        # still runs as 2 x 1 796) but all 10 000 segments of 3 s in one group: BASELINE.json configs[2] 16 001 -> 16 529
+        # segments/s (2 048 per group: 115 launches of the F(4x4) kernel; 3 334: 69, 16 195; 5 000: 46, 16 419; 10 000:
+        # 23 launches).  `max_chunks` / PA_EMB_BATCH (a chunk count) overrides it.
+        env = os.environ.get("PA_EMB_BATCH")
+        self.max_chunks = max_chunks or (int(env) if env else None)
         self._ws = None
         self._idx_cache: dict = {}
 
     # share of the device's FREE memory one launch group's workspace may take (several pipelines / processes on one
     # GPU, or a smaller device, must not run out where the 2 048-chunk default asks for ~62 GB)
     MAX_FREE_FRACTION = 0.4
+    #: workspace of one launch group when no chunk count is given (bytes)
+    GROUP_WORKSPACE_BYTES = 96 << 30
 
     def _group_size(self, num_chunks: int, num_samples: int, S: int) -> int:
-        """chunks per launch group: `max_chunks`, the file split EVENLY over the groups, and halved until the
-        workspace fits MAX_FREE_FRACTION of what is free right now (a cached workspace counts as free)."""
+        """chunks per launch group: `max_chunks` (or as many as GROUP_WORKSPACE_BYTES hold), the file split EVENLY over
+        the groups, and halved until the workspace fits MAX_FREE_FRACTION of what is free right now (a cached workspace
+        counts as free)."""
         lib = ffi.load()
-        groups = -(-num_chunks // self.max_chunks)
+        limit = self.max_chunks
+        if limit is None:
+            # (the workspace is linear in the chunk count up to alignment: measured on 64 chunks)
+            per_chunk = lib.pa_emb_workspace_bytes(self.pack.struct, 64, num_samples, S) / 64.0
+            limit = max(8, int(self.GROUP_WORKSPACE_BYTES / max(per_chunk, 1.0)))
+        groups = -(-num_chunks // limit)
         per_group = -(-num_chunks // groups)
         free, _ = torch.cuda.mem_get_info(self.pack.device)
         # + what torch's caching allocator holds without using it, + this engine's own cached workspace

@@ -256,3 +256,33 @@ def test_fuzz_segmentation_strided(gpu_device, seed):
         top2 = ref.topk(2, dim=-1).values
         safe = (top2[..., 0] - top2[..., 1]) > 1e-4
         assert torch.equal(ml.cpu()[safe], Powerset(3, 2)(ref).to(torch.uint8)[safe]), case
+
+
+def test_one_large_launch_group_equals_many_small_ones(gpu_device):
+    """Since round 6 a launch group of the embedding engine is bounded by its workspace (96 GB), not by a chunk count: 7 000
+    segments of 3 s run as ONE group (7.6e9 activation elements in layer 1: beyond 32-bit element indices) where they
+    used to run as four.  Chunks are independent: the embeddings must be bit-identical to those of groups of 500."""
+    from oracle import seeded_wespeaker
+    from pyannote_audio_amd.embedding import EmbeddingEngine
+    from pyannote_audio_amd.weights import EmbeddingPack
+    model = seeded_wespeaker(seed=4321)
+    pack = EmbeddingPack(model.state_dict(), gpu_device)
+    C, N, step = 7000, 48000, 4000
+    g = torch.Generator().manual_seed(77)
+    wav = (0.1 * torch.randn(step * (C - 1) + N, generator=g)).clamp(-1, 1).to(gpu_device)
+    masks = (torch.rand(C, 3, 173, generator=g) < 0.7).float().to(gpu_device)
+    big = EmbeddingEngine(pack)
+    assert big._group_size(C, N, 3) == C                      # one group
+    small = EmbeddingEngine(pack, max_chunks=500)
+    a = big.forward_strided(wav, step, C, N, masks)
+    big.release_workspace()
+    b = small.forward_strided(wav, step, C, N, masks)
+    torch.cuda.synchronize()
+    assert a.shape == (C, 3, 256) and not torch.isnan(a).any()
+    assert torch.equal(a, b)
+    # ... and a handful of them against the oracle
+    idx = [0, 1, 3499, 6999]
+    chunks = torch.stack([wav[i * step: i * step + N].cpu() for i in idx]).unsqueeze(1)
+    with torch.inference_mode():
+        ref = model(chunks, weights=masks[idx].cpu())
+    assert north_star_ratio("large_group_vs_oracle", a[idx], ref) <= 1.0
