@@ -324,6 +324,10 @@ def bench_ingest(pipeline, wav: torch.Tensor, device, hours: float, reps: int = 
         del w
 
     def one(waveform, tag):
+        # one untimed call first: apply() runs on the default stream, apply_batch's tail on a side stream, and torch's
+        # caching allocator keeps a pool per stream -- the first plain calls behind a batch pay ~25 ms of hipMalloc
+        # for the 206-MB condensed distance matrix (tools/single_file_phases.py, profiles/r6_single_file_phases.txt)
+        pipeline({"waveform": waveform, "sample_rate": 16000, "uri": f"ingest_{tag}_warm"})
         best = None
         for i in range(reps):
             torch.cuda.synchronize()
@@ -342,6 +346,55 @@ def bench_ingest(pipeline, wav: torch.Tensor, device, hours: float, reps: int = 
                                      "ms_per_file": round(1e3 * resident_s, 1)},
             "note": "pipeline(file) one call at a time (nothing overlaps), best of %d; `value` of the line is the "
                     "pipelined stream of HBM-resident files" % reps}
+
+
+def bench_sparse_speech(pipeline, wav: torch.Tensor, hours: float, period_s: int = 120, pause_s: int = 60):
+    """A recording that is half pauses (every `period_s` seconds the last `pause_s` are digital silence): the chunks in
+    which no speaker is active skip the embedding backbone (SpeakerDiarization._embed_speech_chunks; their embeddings
+    cannot change any output) -- `pipeline(file)` one call at a time with the skip (the default) and without it (what
+    the reference computes).  Never `value`: the headline file has no pauses and embeds every chunk."""
+    sparse = wav.clone()
+    n = sparse.shape[1]
+    for start in range(period_s - pause_s, n // 16000, period_s):
+        sparse[:, start * 16000:(start + pause_s) * 16000] = 0.0
+    file = {"waveform": sparse, "sample_rate": 16000, "uri": "sparse"}
+    out = {"pattern": f"{period_s - pause_s} s of conversation, {pause_s} s of silence, repeated",
+           "note": "the seeded segmentation read-out was calibrated on conversation only and reports speakers in digital "
+                   "silence; the chunks that lie wholly inside a pause are forced to 'nobody' here, which is what a "
+                   "trained model outputs by itself"}
+    keep = pipeline.skip_inactive_chunks
+    inference = pipeline._segmentation
+    plain_slide = inference.slide
+    window = round(inference.duration)
+    inside = [c for c in range(max(0, n // 16000 - window + 1))
+              if c % period_s >= period_s - pause_s and (c + window - 1) // period_s == c // period_s]
+
+    def slide(*args, **kwargs):
+        result = plain_slide(*args, **kwargs)
+        idx = [c for c in inside if c < result.data.shape[0]]
+        result.data[idx] = 0
+        inference.last_device_output[torch.as_tensor(idx, device=inference.last_device_output.device)] = 0
+        return result
+    inference.slide = slide
+    try:
+        for tag, skip in (("with_skip", True), ("without_skip", False)):
+            pipeline.skip_inactive_chunks = skip
+            pipeline(file)
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pipeline(file)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            total, done = pipeline.last_embedded_chunks
+            out[tag] = {"ms_per_file": round(1e3 * best, 1), "audio_hours_per_s": round(hours / best, 4),
+                        "chunks": total, "chunks_through_backbone": done}
+    finally:
+        pipeline.skip_inactive_chunks = keep
+        del inference.slide          # (the instance attribute: the class's method is back)
+    return out
 
 
 def bench_reference_metric(pipeline, wav: torch.Tensor, hours: float, num_files: int = 4):
@@ -590,6 +643,9 @@ def main():
                                    "window, WeSpeaker ResNet34 embeddings, centroid AHC) on "
                                    f"{args.hours:g} h of 16 kHz mono audio per GPU",
                        "chunks_per_file": int((wav.shape[1] - 160000) // 16000 + 1),
+                       # (chunks of the last file, chunks of it that went through the embedding backbone: the skip
+                       #  of chunks without an active speaker never fires on the headline file unless these differ)
+                       "chunks_embedded": list(getattr(pipeline, "last_embedded_chunks", (0, 0))),
                        "files": world,
                        "parallelism": f"file-per-gpu x{world}" + (", joint clustering" if joint else "")},
             "real_time_factor": round(total_hours * 3600.0 / elapsed, 1),
@@ -627,6 +683,7 @@ def main():
             # what a file that starts on the host costs
             line["ingest"] = bench_ingest(pipeline, wav, device, args.hours)
             line["reference_metric"] = bench_reference_metric(pipeline, wav, args.hours)
+            line["sparse_speech"] = bench_sparse_speech(pipeline, wav, args.hours)
             line["configs"] = {}
             for name, (st, wu) in (("seg5s", (4, 1)), ("emb3s", (2, 1))):
                 d = bench_stage(args, pipeline, device, rank, config=name, steps=st, warmup=wu)

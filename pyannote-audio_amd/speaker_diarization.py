@@ -233,8 +233,47 @@ class SpeakerDiarization(Pipeline):
             hook("embeddings", None, total=batches, completed=0)
         wav = waveform.to(self._embedding.device, torch.float32).contiguous().view(-1)
         engine = self._embedding.model_.engine
-        emb = engine.forward_strided(wav[first_chunk * step:], step, C, window, masks)
+        emb = self._embed_speech_chunks(engine, wav[first_chunk * step:], step, C, window, masks)
         return emb, active, clean, batches
+
+    #: chunks in which NO local speaker is active skip the embedding backbone (see `_embed_speech_chunks`);
+    #: PA_EMB_SKIP_INACTIVE=0 or this attribute set to False runs every chunk, as the reference does
+    skip_inactive_chunks: bool = os.environ.get("PA_EMB_SKIP_INACTIVE", "1") != "0"
+    #: what the last `_embed` call did: (chunks of the file, chunks that went through the backbone)
+    last_embedded_chunks: tuple = (0, 0)
+
+    def _embed_speech_chunks(self, engine, wav: torch.Tensor, step: int, C: int, window: int,
+                             masks: torch.Tensor) -> torch.Tensor:
+        """`engine.forward_strided` over the chunks that have at least one non-empty mask.
+
+        The reference embeds every (chunk, speaker) pair (speaker_diarization.py:384-476), silent or not.  A mask
+        that is zero everywhere pools to mean = 0 / 1e-8 and std = 0 whatever the backbone computed
+        (models/blocks/pooling.py:49-61), so its embedding is the bias of the final Linear: the backbone pass of a
+        chunk whose masks are ALL empty cannot change any output.  Such chunks are left out of the launch (the
+        others are gathered into a compact buffer, one copy of 4 * window bytes per chunk); ONE of them is kept as
+        the representative whose rows are written to all of them, so the "embeddings" artefact is what the full
+        run produces, bit for bit (tests/test_pipeline_gpu.py) -- unless a backbone activation of a skipped chunk
+        was not finite (0 * inf = NaN in the full run)."""
+        self.last_embedded_chunks = (C, C)
+        if not self.skip_inactive_chunks or masks is None or C < 3:
+            return engine.forward_strided(wav, step, C, window, masks)
+        speech = masks.flatten(1).any(dim=1)                       # (C,) on the device
+        kept = torch.nonzero(speech).view(-1)
+        num_kept = int(kept.numel())       # (host wait: the segmentation stage left the device before this call)
+        if C - num_kept < 2:               # one silent chunk = the representative: nothing to save
+            return engine.forward_strided(wav, step, C, window, masks)
+        silent = torch.nonzero(~speech).view(-1)
+        sel = torch.cat([kept, silent[:1]])
+        need = (C - 1) * step + window
+        if wav.numel() < need:             # the last chunk runs past the file: zeros, as the kernels assume
+            wav = torch.nn.functional.pad(wav, (0, need - wav.numel()))
+        compact = wav.unfold(0, window, step)[sel].contiguous()    # (num_kept + 1, window)
+        out = engine.forward_strided(compact.view(-1), window, int(sel.numel()), window, masks[sel].contiguous())
+        emb = torch.empty((C,) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+        emb[silent] = out[-1]
+        emb[kept] = out[:-1]
+        self.last_embedded_chunks = (C, num_kept + 1)
+        return emb
 
     def get_embeddings(self, file, binary_segmentations: SlidingWindowFeature,
                        exclude_overlap: bool = False, hook: Optional[Callable] = None,

@@ -346,3 +346,84 @@ def test_non_powerset_pipeline_matches_oracle(synthetic_models, gpu_device, tmp_
     with torch.inference_mode():
         ref = seg_o(chunk)
     assert north_star_ratio("non_powerset_forward", model(chunk.to(gpu_device)), ref) <= 1.0
+
+
+def test_inactive_chunks_skip_the_backbone_bit_identically(pipeline_dir, gpu_device):
+    """chunks whose masks are all empty are left out of the embedding launch (SpeakerDiarization._embed_speech_chunks):
+    every row equals the row of the full run, bit for bit -- the kept chunks although they were computed in another
+    launch composition, the skipped ones because an empty mask pools to zero whatever the backbone computed"""
+    import pyannote_audio_amd as pa
+    from oracle.synthetic import synth_conversation
+    wav, _ = synth_conversation(41.5, seed=3)            # 33 chunks, the last one runs past the file
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir)
+    pipeline.to(gpu_device)
+    waveform = wav.to(gpu_device)
+    seg = pipeline.get_segmentations({"waveform": wav, "sample_rate": 16000, "uri": "s"}, waveform=waveform)
+    dev_seg = pipeline._segmentation.last_device_output.clone()
+    C = dev_seg.shape[0]
+    assert C >= 30
+    silent = [0, 7, 8, 9, 10, 11, 19, C - 1]             # first, last (zero-padded) and interior chunks
+    dev_seg[silent] = 0
+    for exclude_overlap in (True, False):
+        pipeline.skip_inactive_chunks = False
+        full, *_ = pipeline._embed(waveform, dev_seg, seg.sliding_window, 0, exclude_overlap, None)
+        assert pipeline.last_embedded_chunks == (C, C)
+        pipeline.skip_inactive_chunks = True
+        short, *_ = pipeline._embed(waveform, dev_seg, seg.sliding_window, 0, exclude_overlap, None)
+        kept = int(dev_seg.flatten(1).any(dim=1).sum())
+        assert kept <= C - len(silent) and pipeline.last_embedded_chunks == (C, kept + 1)
+        assert torch.isfinite(full).all()
+        assert torch.equal(full, short)
+        # (an empty mask gives the bias of the last Linear: the same row everywhere)
+        assert torch.equal(short[silent[0]], short[silent[-1]])
+    # nothing to skip: the plain launch
+    dev_seg = pipeline._segmentation.last_device_output
+    if bool(dev_seg.flatten(1).any(dim=1).all()):
+        pipeline._embed(waveform, dev_seg, seg.sliding_window, 0, True, None)
+        assert pipeline.last_embedded_chunks == (C, C)
+
+
+def test_pipeline_over_a_long_pause_equals_the_full_run(pipeline_dir, gpu_device):
+    """a recording with 45 s of silence in the middle: the pipeline's outputs with and without the skip are the same
+    objects (turns, labels, centroids, the "embeddings" artefact)"""
+    import pyannote_audio_amd as pa
+    from oracle.synthetic import synth_conversation
+    a, _ = synth_conversation(24.0, seed=11)
+    b, _ = synth_conversation(21.0, seed=12)
+    wav = torch.cat([a, torch.zeros(1, 45 * 16000), b], dim=1)
+    pipeline = pa.Pipeline.from_pretrained(pipeline_dir)
+    pipeline.to(gpu_device)
+    # the seeded read-out was calibrated on conversation only and finds speakers in digital silence (a trained model does
+    # not): the chunks that lie inside the pause are forced to "nobody", on the host copy and on the device copy alike
+    inference = pipeline._segmentation
+    plain_slide = inference.slide
+
+    def slide(*args, **kwargs):
+        out = plain_slide(*args, **kwargs)
+        out.data[24:60] = 0
+        inference.last_device_output[24:60] = 0
+        return out
+    inference.slide = slide
+
+    def run(skip):
+        pipeline.skip_inactive_chunks = skip
+        art = {}
+
+        def hook(step, artifact, file=None, total=None, completed=None):
+            if artifact is not None and total is None:
+                import copy
+                art[step] = copy.deepcopy(artifact)
+        out = pipeline({"waveform": wav, "sample_rate": 16000, "uri": "pause"}, hook=hook)
+        return out, art, pipeline.last_embedded_chunks
+
+    full, art_full, done_full = run(False)
+    short, art_short, done_short = run(True)
+    assert done_full[0] == done_full[1] and done_short[0] == done_full[0]
+    with open("gpurun_out/parity.log", "a") as fp:
+        fp.write(f"pipeline[long pause]: chunks through the backbone {done_short[1]} of {done_short[0]}\n")
+    assert done_short[1] <= done_short[0] - 35
+    assert np.array_equal(art_full["embeddings"], art_short["embeddings"])
+    turns = lambda o: [(s.start, s.end, l) for s, _, l in o.itertracks(yield_label=True)]
+    assert turns(full.speaker_diarization) == turns(short.speaker_diarization)
+    assert turns(full.exclusive_speaker_diarization) == turns(short.exclusive_speaker_diarization)
+    assert np.array_equal(full.speaker_embeddings, short.speaker_embeddings)
