@@ -16,6 +16,8 @@ shapes = [  # (H, W, cin, cout, stride, residual)
     (10, 125, 256, 256, 1, True)]
 if os.environ.get("ONLY_S1") == "1":   # the stride-1 (Winograd) layers, with and without the residual input
     shapes = [(H, W, ci, co, s, r) for (H, W, ci, co, s, _) in shapes if s == 1 for r in (False, True)]
+if os.environ.get("ONLY_CIN"):         # one input width only (e.g. ONLY_CIN=32: layer 1)
+    shapes = [sh for sh in shapes if sh[2] == int(os.environ["ONLY_CIN"])]
 for (H, W, ci, co, s, res) in shapes:
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     X = torch.randn(B, H, W, ci, device=dev)
