@@ -58,6 +58,16 @@ def test_xvector_strided_chunks_and_too_short(xvec, gpu_device):
         want = torch.stack([model(chunks, weights=masks[:, s]) for s in range(3)], dim=1)
     got = eng.forward_strided(wav.to(gpu_device), step, C, N, masks.to(gpu_device))
     assert north_star_ratio("xvector_strided", got, want) <= 1.0
+    # chunks whose masks are all empty skip the backbone (SpeakerDiarization._embed_speech_chunks): same rows, bit for bit
+    from types import SimpleNamespace
+    from pyannote_audio_amd.speaker_diarization import SpeakerDiarization
+    sparse = masks.clone()
+    sparse[[0, 3, 4, C - 1]] = 0.0
+    wd, md = wav.to(gpu_device), sparse.to(gpu_device)
+    me = SimpleNamespace(skip_inactive_chunks=True, last_embedded_chunks=(0, 0))
+    short = SpeakerDiarization._embed_speech_chunks(me, eng, wd, step, C, N, md)
+    assert me.last_embedded_chunks == (C, C - 4 + 1)
+    assert torch.equal(short, eng.forward_strided(wd, step, C, N, md))
     assert eng.num_pool_frames(4770) == 0 and eng.num_pool_frames(4771) == 1
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(1, 1, 4770, device=gpu_device))
