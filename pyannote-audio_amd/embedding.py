@@ -25,10 +25,12 @@ class EmbeddingEngine:
         # kernel 0.55 -> 0.62 of peak); groups sized to the 256-MiB Infinity Cache (8 chunks, so that a convolution
         # would read its predecessor's output on-die) are far on the wrong side of that trade.  The chunks of a
         # file are split EVENLY over the groups (3 591 = 2 x 1 796).
-        # Round 6: the limit is a WORKSPACE SIZE, not a chunk count -- 96 GB, i.e. 3 096 chunks of 10 s (a one-hour file
-        # still runs as 2 x 1 796) but all 10 000 segments of 3 s in one group: BASELINE.json configs[2] 16 001 -> 16 529
-        # segments/s (2 048 per group: 115 launches of the F(4x4) kernel; 3 334: 69, 16 195; 5 000: 46, 16 419; 10 000:
-        # 23 launches).  `max_chunks` / PA_EMB_BATCH (a chunk count) overrides it.
+        # Round 6: the limit is a WORKSPACE SIZE, not a chunk count -- all 10 000 segments of 3 s in one group:
+        # BASELINE.json configs[2] 16 001 -> 16 529 segments/s (2 048 per group: 115 launches of the F(4x4) kernel; 3 334:
+        # 69, 16 195; 5 000: 46, 16 419; 10 000: 23 launches).  First 96 GB (a one-hour file = 2 x 1 796 chunks), then 128 GB:
+        # the 3 591 chunks of a one-hour file in ONE group (111 GB) measured 757.1 / 757.6 ms per file against 760.6 / 765.6
+        # as two groups and 766.6 / 769.9 as three (A/B pairs in one call, profiles/r6_emb_group_ab.txt).
+        # `max_chunks` / PA_EMB_BATCH (a chunk count) overrides it.
         env = os.environ.get("PA_EMB_BATCH")
         self.max_chunks = max_chunks or (int(env) if env else None)
         self._ws = None
@@ -36,9 +38,9 @@ class EmbeddingEngine:
 
     # share of the device's FREE memory one launch group's workspace may take (several pipelines / processes on one
     # GPU, or a smaller device, must not run out where the 2 048-chunk default asks for ~62 GB)
-    MAX_FREE_FRACTION = 0.4
+    MAX_FREE_FRACTION = 0.5
     #: workspace of one launch group when no chunk count is given (bytes)
-    GROUP_WORKSPACE_BYTES = 96 << 30
+    GROUP_WORKSPACE_BYTES = 128 << 30
 
     def _group_size(self, num_chunks: int, num_samples: int, S: int) -> int:
         """chunks per launch group: `max_chunks` (or as many as GROUP_WORKSPACE_BYTES hold), the file split EVENLY over

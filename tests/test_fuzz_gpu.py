@@ -264,7 +264,7 @@ def test_fuzz_segmentation_strided(gpu_device, seed):
 
 
 def test_one_large_launch_group_equals_many_small_ones(gpu_device):
-    """Since round 6 a launch group of the embedding engine is bounded by its workspace (96 GB), not by a chunk count: 7 000
+    """Since round 6 a launch group of the embedding engine is bounded by its workspace (128 GB; 96 GB at first), not by a chunk count: 7 000
     segments of 3 s run as ONE group (7.6e9 activation elements in layer 1: beyond 32-bit element indices) where they
     used to run as four.  Chunks are independent: the embeddings must be bit-identical to those of groups of 500."""
     from oracle import seeded_wespeaker
